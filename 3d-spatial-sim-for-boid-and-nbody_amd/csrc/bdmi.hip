@@ -1,0 +1,528 @@
+// Boids fixed-radius neighbour sweep on MI355X (gfx950).  C ABI in include/bdmi.h.
+//
+// One bdmi_step == one Flock.update(dt) of the reference (boids/flock.py:627-678):
+//   assign_cells (:30-44) -> argsort + build_cell_lists (:610-625, :47-65) ->
+//   compute_flocking_spatial (:68-238) -> update_physics_numba (:241-308).
+// float64 state and arithmetic like the reference (this path is bandwidth bound; MI355X
+// float64 vector rate is far above what ~7 candidates per boid need).
+//
+// HBM layout: SoA float64 {p, v, c} x 3 + int32 id, kept in CELL-SORTED order between steps
+// (buffer A).  Per step: cell keys from A -> radix sort (cell, rank) -> gather A into B in the
+// new order -> dense cell table (start, end) from the sorted keys -> sweep kernel reads
+// neighbours from B (contiguous per cell, and the three x-adjacent cells of a row are
+// contiguous too) and writes the updated boid back to A at the same rank, physics fused.
+#include <stddef.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/bdmi.h"
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Boids {
+    double *px, *py, *pz, *vx, *vy, *vz, *cr, *cg, *cb;
+    int32_t *id;
+};
+
+struct GridP {
+    double cell_size, offset;
+    int dim, range;
+};
+
+struct FlockP {
+    double perception_sq, separation_sq, sep_w, ali_w, coh_w, max_speed, max_force;
+    double bounds, margin, wall_force, blend, dt;
+};
+
+// get_cell_index (flock.py:16-27): int() truncation toward zero, then clamp
+__device__ __forceinline__ int cell_coord(double v, const GridP &g) {
+    int c = (int)((v + g.offset) / g.cell_size);
+    c = c < 0 ? 0 : c;
+    c = c > g.dim - 1 ? g.dim - 1 : c;
+    return c;
+}
+
+__global__ __launch_bounds__(kBlock) void k_assign(Boids a, int64_t n, GridP g, uint32_t *__restrict__ keys,
+                                                   uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int cx = cell_coord(a.px[i], g), cy = cell_coord(a.py[i], g), cz = cell_coord(a.pz[i], g);
+    keys[i] = (uint32_t)(cx + cy * g.dim + cz * g.dim * g.dim);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_reorder(Boids a, Boids b, const uint32_t *__restrict__ perm, int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t j = perm[r];
+    b.px[r] = a.px[j]; b.py[r] = a.py[j]; b.pz[r] = a.pz[j];
+    b.vx[r] = a.vx[j]; b.vy[r] = a.vy[j]; b.vz[r] = a.vz[j];
+    b.cr[r] = a.cr[j]; b.cg[r] = a.cg[j]; b.cb[r] = a.cb[j];
+    b.id[r] = a.id[j];
+}
+
+// build_cell_lists (flock.py:47-65) from sorted keys: start (-1 if empty) and end per cell
+__global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
+                                                  int32_t *__restrict__ cell_start, int32_t *__restrict__ cell_end,
+                                                  unsigned long long *occupied) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t c = keys_s[r];
+    if (r == 0 || keys_s[r - 1] != c) {
+        cell_start[c] = (int32_t)r;
+        atomicAdd(occupied, 1ull);
+    }
+    if (r == n - 1 || keys_s[r + 1] != c) cell_end[c] = (int32_t)(r + 1);
+}
+
+// steer(): mean -> normalise * max_speed - v -> clamp to max_force -> * weight
+// (the repeated block of flock.py:174-234); returns false if the magnitude is 0.
+__device__ __forceinline__ bool steer(double &x, double &y, double &z, double vx, double vy, double vz,
+                                      double max_speed, double max_force, double w) {
+    double mag = sqrt(x * x + y * y + z * z);
+    if (!(mag > 0)) return false;
+    x = (x / mag) * max_speed - vx;
+    y = (y / mag) * max_speed - vy;
+    z = (z / mag) * max_speed - vz;
+    mag = sqrt(x * x + y * y + z * z);
+    if (mag > max_force) {
+        x = (x / mag) * max_force;
+        y = (y / mag) * max_force;
+        z = (z / mag) * max_force;
+    }
+    x *= w; y *= w; z *= w;
+    return true;
+}
+
+// compute_flocking_spatial (flock.py:68-238) + update_physics_numba (flock.py:241-308).
+// kPhysics=false: write the four force arrays (caller's boid order) instead of integrating.
+template <bool kPhysics>
+__global__ __launch_bounds__(kBlock) void k_flock(Boids b, Boids a, const int32_t *__restrict__ cell_start,
+                                                  const int32_t *__restrict__ cell_end, int64_t n, GridP g, FlockP P,
+                                                  double *__restrict__ o_sep, double *__restrict__ o_ali,
+                                                  double *__restrict__ o_coh, double *__restrict__ o_avg) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const double pix = b.px[r], piy = b.py[r], piz = b.pz[r];
+    const double vix = b.vx[r], viy = b.vy[r], viz = b.vz[r];
+    const double cir = b.cr[r], cig = b.cg[r], cib = b.cb[r];
+    const int cx = cell_coord(pix, g), cy = cell_coord(piy, g), cz = cell_coord(piz, g);
+    double sx = 0, sy = 0, sz = 0, alx = 0, aly = 0, alz = 0, cox = 0, coy = 0, coz = 0, clr = 0, clg = 0, clb = 0;
+    int sep_count = 0, nb_count = 0;
+    for (int dcx = -g.range; dcx <= g.range; dcx++) {
+        const int ncx = cx + dcx;
+        if (ncx < 0 || ncx >= g.dim) continue;
+        for (int dcy = -g.range; dcy <= g.range; dcy++) {
+            const int ncy = cy + dcy;
+            if (ncy < 0 || ncy >= g.dim) continue;
+            for (int dcz = -g.range; dcz <= g.range; dcz++) {
+                const int ncz = cz + dcz;
+                if (ncz < 0 || ncz >= g.dim) continue;
+                const int64_t cell = ncx + (int64_t)ncy * g.dim + (int64_t)ncz * g.dim * g.dim;
+                const int32_t start = cell_start[cell];
+                if (start < 0) continue;
+                const int32_t end = cell_end[cell];
+                for (int32_t q = start; q < end; q++) {
+                    if (q == r) continue;
+                    const double qx = b.px[q], qy = b.py[q], qz = b.pz[q];
+                    const double dx = pix - qx, dy = piy - qy, dz = piz - qz;
+                    const double dist_sq = dx * dx + dy * dy + dz * dz;
+                    if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
+                        const double dist = sqrt(dist_sq);
+                        if (dist_sq < P.separation_sq) {
+                            const double inv_dist = 1.0 / dist;
+                            sx += dx * inv_dist / dist;
+                            sy += dy * inv_dist / dist;
+                            sz += dz * inv_dist / dist;
+                            sep_count++;
+                        }
+                        alx += b.vx[q]; aly += b.vy[q]; alz += b.vz[q];
+                        cox += qx; coy += qy; coz += qz;
+                        clr += b.cr[q]; clg += b.cg[q]; clb += b.cb[q];
+                        nb_count++;
+                    }
+                }
+            }
+        }
+    }
+    double fsx = 0, fsy = 0, fsz = 0, fax = 0, fay = 0, faz = 0, fcx = 0, fcy = 0, fcz = 0;
+    double avr = cir, avg = cig, avb = cib;  // caller pre-fill: avg_colors <- colors (flock.py:636)
+    if (sep_count > 0) {
+        sx /= sep_count; sy /= sep_count; sz /= sep_count;
+        if (steer(sx, sy, sz, vix, viy, viz, P.max_speed, P.max_force, P.sep_w)) { fsx = sx; fsy = sy; fsz = sz; }
+    }
+    if (nb_count > 0) {
+        alx /= nb_count; aly /= nb_count; alz /= nb_count;
+        if (steer(alx, aly, alz, vix, viy, viz, P.max_speed, P.max_force, P.ali_w)) { fax = alx; fay = aly; faz = alz; }
+        cox = cox / nb_count - pix; coy = coy / nb_count - piy; coz = coz / nb_count - piz;
+        if (steer(cox, coy, coz, vix, viy, viz, P.max_speed, P.max_force, P.coh_w)) { fcx = cox; fcy = coy; fcz = coz; }
+        avr = (clr + cir) / (nb_count + 1);
+        avg = (clg + cig) / (nb_count + 1);
+        avb = (clb + cib) / (nb_count + 1);
+    }
+    if (!kPhysics) {
+        const int64_t o = 3 * (int64_t)b.id[r];
+        o_sep[o] = fsx; o_sep[o + 1] = fsy; o_sep[o + 2] = fsz;
+        o_ali[o] = fax; o_ali[o + 1] = fay; o_ali[o + 2] = faz;
+        o_coh[o] = fcx; o_coh[o + 1] = fcy; o_coh[o + 2] = fcz;
+        o_avg[o] = avr; o_avg[o + 1] = avg; o_avg[o + 2] = avb;
+        return;
+    }
+    double acc[3] = {fsx + fax + fcx, fsy + fay + fcy, fsz + faz + fcz};
+    const double pos[3] = {pix, piy, piz};
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const double dist_pos = pos[d] - (P.bounds - P.margin);
+        if (dist_pos > 0) acc[d] -= fmin(dist_pos / P.margin * 2.0, 1.0) * P.wall_force;
+        const double dist_neg = (-P.bounds + P.margin) - pos[d];
+        if (dist_neg > 0) acc[d] += fmin(dist_neg / P.margin * 2.0, 1.0) * P.wall_force;
+    }
+    double nvx = vix + acc[0] * P.dt, nvy = viy + acc[1] * P.dt, nvz = viz + acc[2] * P.dt;
+    const double speed = sqrt(nvx * nvx + nvy * nvy + nvz * nvz);
+    if (speed > P.max_speed) {
+        const double scale = P.max_speed / speed;
+        nvx *= scale; nvy *= scale; nvz *= scale;
+    }
+    a.vx[r] = nvx; a.vy[r] = nvy; a.vz[r] = nvz;
+    a.px[r] = pix + nvx * P.dt; a.py[r] = piy + nvy * P.dt; a.pz[r] = piz + nvz * P.dt;
+    a.cr[r] = cir + (avr - cir) * P.blend;
+    a.cg[r] = cig + (avg - cig) * P.blend;
+    a.cb[r] = cib + (avb - cib) * P.blend;
+    a.id[r] = b.id[r];
+}
+
+__global__ __launch_bounds__(kBlock) void k_split(const double *__restrict__ p, const double *__restrict__ v,
+                                                  const double *__restrict__ c, Boids a, int64_t n, int by_id) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t i = by_id ? (int64_t)a.id[r] : r;
+    if (p) { a.px[r] = p[3 * i]; a.py[r] = p[3 * i + 1]; a.pz[r] = p[3 * i + 2]; }
+    if (v) { a.vx[r] = v[3 * i]; a.vy[r] = v[3 * i + 1]; a.vz[r] = v[3 * i + 2]; }
+    if (c) { a.cr[r] = c[3 * i]; a.cg[r] = c[3 * i + 1]; a.cb[r] = c[3 * i + 2]; }
+    if (!by_id) a.id[r] = (int32_t)r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_join(const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, const int32_t *__restrict__ id, int64_t n,
+                                                 double *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t o = 3 * (int64_t)id[r];
+    out[o] = x[r]; out[o + 1] = y[r]; out[o + 2] = z[r];
+}
+
+__global__ __launch_bounds__(kBlock) void k_cells_out(Boids a, int64_t n, GridP g, int32_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int cx = cell_coord(a.px[r], g), cy = cell_coord(a.py[r], g), cz = cell_coord(a.pz[r], g);
+    out[a.id[r]] = cx + cy * g.dim + cz * g.dim * g.dim;
+}
+
+inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+struct bdmi_flock {
+    int64_t n = 0;
+    int device = 0;
+    double params[11] = {};
+    GridP grid = {};
+    int64_t num_cells = 0;
+    int key_bits = 0;
+    hipStream_t stream = nullptr;
+    Boids A = {}, B = {};
+    uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *perm = nullptr;
+    int32_t *cell_start = nullptr, *cell_end = nullptr;
+    unsigned long long *occupied = nullptr;
+    void *tmp_sort = nullptr;
+    size_t tmp_sort_bytes = 0;
+    double *stage = nullptr;  // 12 N doubles
+    bool timers = false;
+    hipEvent_t ev[4] = {};
+    double ms[3] = {0, 0, 0};
+    int64_t timed = 0;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(bdmi_flock *f, T **p, size_t count) {
+    void *q = nullptr;
+    NBMI_HIP_CHECK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    f->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+int alloc_boids(bdmi_flock *f, Boids *b, int64_t n) {
+    if (dev_alloc(f, &b->px, n) || dev_alloc(f, &b->py, n) || dev_alloc(f, &b->pz, n) || dev_alloc(f, &b->vx, n) ||
+        dev_alloc(f, &b->vy, n) || dev_alloc(f, &b->vz, n) || dev_alloc(f, &b->cr, n) || dev_alloc(f, &b->cg, n) ||
+        dev_alloc(f, &b->cb, n) || dev_alloc(f, &b->id, n))
+        return -2;
+    return 0;
+}
+
+int check(bdmi_flock *f) {
+    if (!f) { nbmi::set_error("null bdmi_flock handle"); return -1; }
+    if (hipSetDevice(f->device) != hipSuccess) { nbmi::set_error("hipSetDevice(%d) failed", f->device); return -2; }
+    return 0;
+}
+
+FlockP make_params(const bdmi_flock *f, double dt) {
+    const double *p = f->params;
+    FlockP P;
+    P.bounds = p[0]; P.margin = p[1];
+    P.max_speed = p[3]; P.max_force = p[4];
+    P.wall_force = p[4] * p[2];  // max_force * wall_weight (flock.py:673)
+    P.perception_sq = p[5] * p[5];
+    P.separation_sq = p[6] * p[6];
+    P.sep_w = p[7]; P.ali_w = p[8]; P.coh_w = p[9];
+    const double blend = p[10] * dt;  // min(1, color_blend_rate * dt) (flock.py:662)
+    P.blend = blend < 1.0 ? blend : 1.0;
+    P.dt = dt;
+    return P;
+}
+
+// cells -> sort -> reorder A->B -> table
+int enqueue_grid(bdmi_flock *f, bool timed) {
+    const int64_t n = f->n;
+    hipStream_t st = f->stream;
+    if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[0], st));
+    k_assign<<<nblocks(n), kBlock, 0, st>>>(f->A, n, f->grid, f->keys, f->idx);
+    NBMI_HIP_CHECK(nbmi::sort_pairs_u32_u32(f->tmp_sort, f->tmp_sort_bytes, f->keys, f->keys_s, f->idx, f->perm,
+                                            (size_t)n, 0, f->key_bits, st));
+    if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[1], st));
+    k_reorder<<<nblocks(n), kBlock, 0, st>>>(f->A, f->B, f->perm, n);
+    NBMI_HIP_CHECK(hipMemsetAsync(f->cell_start, 0xff, (size_t)f->num_cells * sizeof(int32_t), st));
+    NBMI_HIP_CHECK(hipMemsetAsync(f->occupied, 0, sizeof(unsigned long long), st));
+    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->cell_start, f->cell_end, f->occupied);
+    if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[2], st));
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *bdmi_last_error(void) { return nbmi::get_error(); }
+
+void bdmi_destroy(bdmi_flock *f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    for (void *p : f->allocs) (void)hipFree(p);
+    for (auto &e : f->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+}
+
+static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, const double *col) {
+    const int64_t n = f->n;
+    NBMI_HIP_CHECK(hipSetDevice(f->device));
+    NBMI_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
+    for (auto &e : f->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
+    if (alloc_boids(f, &f->A, n) || alloc_boids(f, &f->B, n)) return -2;
+    if (dev_alloc(f, &f->keys, n) || dev_alloc(f, &f->keys_s, n) || dev_alloc(f, &f->idx, n) ||
+        dev_alloc(f, &f->perm, n) || dev_alloc(f, &f->cell_start, (size_t)f->num_cells) ||
+        dev_alloc(f, &f->cell_end, (size_t)f->num_cells) || dev_alloc(f, &f->occupied, 1) ||
+        dev_alloc(f, &f->stage, (size_t)12 * (n ? n : 1)))
+        return -2;
+    f->tmp_sort_bytes = nbmi::sort_pairs32_temp_bytes((size_t)n, 0, f->key_bits);
+    char *t = nullptr;
+    if (dev_alloc(f, &t, f->tmp_sort_bytes + 256)) return -2;
+    f->tmp_sort = t;
+    if (n > 0) {
+        double *dp = f->stage, *dv = dp + 3 * n, *dc = dv + 3 * n;
+        NBMI_HIP_CHECK(hipMemcpyAsync(dp, pos, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+        NBMI_HIP_CHECK(hipMemcpyAsync(dv, vel, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+        NBMI_HIP_CHECK(hipMemcpyAsync(dc, col, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+        k_split<<<nblocks(n), kBlock, 0, f->stream>>>(dp, dv, dc, f->A, n, 0);
+        NBMI_HIP_CHECK(hipGetLastError());
+    }
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const double *col, const double *params,
+                        int device) {
+    nbmi::clear_error();
+    if (n < 0 || n > 1000000000 || !params || (n > 0 && (!pos || !vel || !col))) {
+        nbmi::set_error("bdmi_create: bad arguments (n=%lld)", (long long)n);
+        return nullptr;
+    }
+    const double bounds = params[0], perception = params[5], margin = params[1];
+    if (!(bounds > 0) || !(perception > 0) || !(margin > 0)) {
+        nbmi::set_error("bdmi_create: bounds, perception_radius and wall_margin must be > 0");
+        return nullptr;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        nbmi::set_error("bdmi_create: no HIP device available");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        nbmi::set_error("bdmi_create: device %d out of range (have %d)", device, count);
+        return nullptr;
+    }
+    bdmi_flock *f = new bdmi_flock();
+    f->n = n;
+    f->device = device;
+    memcpy(f->params, params, sizeof(f->params));
+    // Flock.__init__ grid (flock.py:478-481)
+    f->grid.cell_size = perception;
+    const double dimf = ceil(bounds * 2 / perception) + 2;
+    if (!(dimf >= 1) || dimf > 1290) {  // dim^3 must fit int32 cell ids
+        nbmi::set_error("bdmi_create: grid dimension %.0f out of range", dimf);
+        delete f;
+        return nullptr;
+    }
+    f->grid.dim = (int)dimf;
+    f->grid.offset = bounds + perception;
+    f->grid.range = (int)ceil(perception / f->grid.cell_size);
+    f->num_cells = (int64_t)f->grid.dim * f->grid.dim * f->grid.dim;
+    f->key_bits = 1;
+    while (((int64_t)1 << f->key_bits) < f->num_cells) f->key_bits++;
+    if (bd_create_impl(f, pos, vel, col) != 0) {
+        std::string keep = nbmi::get_error();
+        bdmi_destroy(f);
+        nbmi::set_error("%s", keep.c_str());
+        return nullptr;
+    }
+    return f;
+}
+
+int bdmi_step(bdmi_flock *f, double dt, int substeps) {
+    if (int rc = check(f)) return rc;
+    if (substeps < 0) { nbmi::set_error("bdmi_step: substeps < 0"); return -1; }
+    if (f->n == 0) return 0;
+    const FlockP P = make_params(f, dt);
+    for (int k = 0; k < substeps; k++) {
+        if (int rc = enqueue_grid(f, f->timers)) return rc;
+        k_flock<true><<<nblocks(f->n), kBlock, 0, f->stream>>>(f->B, f->A, f->cell_start, f->cell_end, f->n, f->grid, P,
+                                                               nullptr, nullptr, nullptr, nullptr);
+        NBMI_HIP_CHECK(hipGetLastError());
+        if (f->timers) {
+            NBMI_HIP_CHECK(hipEventRecord(f->ev[3], f->stream));
+            NBMI_HIP_CHECK(hipEventSynchronize(f->ev[3]));
+            for (int p = 0; p < 3; p++) {
+                float ms = 0.f;
+                NBMI_HIP_CHECK(hipEventElapsedTime(&ms, f->ev[p], f->ev[p + 1]));
+                f->ms[p] += ms;
+            }
+            f->timed++;
+        }
+    }
+    return 0;
+}
+
+int bdmi_sync(bdmi_flock *f) {
+    if (int rc = check(f)) return rc;
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int bdmi_get_state(bdmi_flock *f, double *pos, double *vel, double *col) {
+    if (int rc = check(f)) return rc;
+    const int64_t n = f->n;
+    if (n == 0) return 0;
+    double *dp = f->stage, *dv = dp + 3 * n, *dc = dv + 3 * n;
+    const Boids &a = f->A;
+    if (pos) {
+        k_join<<<nblocks(n), kBlock, 0, f->stream>>>(a.px, a.py, a.pz, a.id, n, dp);
+        NBMI_HIP_CHECK(hipMemcpyAsync(pos, dp, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    }
+    if (vel) {
+        k_join<<<nblocks(n), kBlock, 0, f->stream>>>(a.vx, a.vy, a.vz, a.id, n, dv);
+        NBMI_HIP_CHECK(hipMemcpyAsync(vel, dv, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    }
+    if (col) {
+        k_join<<<nblocks(n), kBlock, 0, f->stream>>>(a.cr, a.cg, a.cb, a.id, n, dc);
+        NBMI_HIP_CHECK(hipMemcpyAsync(col, dc, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    }
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int bdmi_set_state(bdmi_flock *f, const double *pos, const double *vel, const double *col) {
+    if (int rc = check(f)) return rc;
+    const int64_t n = f->n;
+    if (n == 0) return 0;
+    double *dp = f->stage, *dv = dp + 3 * n, *dc = dv + 3 * n;
+    if (pos) NBMI_HIP_CHECK(hipMemcpyAsync(dp, pos, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+    if (vel) NBMI_HIP_CHECK(hipMemcpyAsync(dv, vel, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+    if (col) NBMI_HIP_CHECK(hipMemcpyAsync(dc, col, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
+    k_split<<<nblocks(n), kBlock, 0, f->stream>>>(pos ? dp : nullptr, vel ? dv : nullptr, col ? dc : nullptr, f->A, n, 1);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int bdmi_get_cell_indices(bdmi_flock *f, int32_t *out) {
+    if (int rc = check(f)) return rc;
+    const int64_t n = f->n;
+    if (n == 0) return 0;
+    if (!out) { nbmi::set_error("null output"); return -1; }
+    int32_t *d = (int32_t *)f->stage;
+    k_cells_out<<<nblocks(n), kBlock, 0, f->stream>>>(f->A, n, f->grid, d);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int bdmi_get_forces(bdmi_flock *f, double *sep, double *ali, double *coh, double *avg) {
+    if (int rc = check(f)) return rc;
+    const int64_t n = f->n;
+    if (n == 0) return 0;
+    if (!sep || !ali || !coh || !avg) { nbmi::set_error("null output"); return -1; }
+    if (int rc = enqueue_grid(f, false)) return rc;
+    double *d0 = f->stage, *d1 = d0 + 3 * n, *d2 = d1 + 3 * n, *d3 = d2 + 3 * n;
+    const FlockP P = make_params(f, 0.0);
+    k_flock<false><<<nblocks(n), kBlock, 0, f->stream>>>(f->B, f->A, f->cell_start, f->cell_end, n, f->grid, P, d0, d1,
+                                                         d2, d3);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(sep, d0, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(ali, d1, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(coh, d2, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(avg, d3, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    return 0;
+}
+
+int bdmi_grid_info(bdmi_flock *f, int32_t *grid_dim, int64_t *num_cells, int64_t *occupied) {
+    if (int rc = check(f)) return rc;
+    if (grid_dim) *grid_dim = f->grid.dim;
+    if (num_cells) *num_cells = f->num_cells;
+    if (occupied) {
+        unsigned long long h = 0;
+        NBMI_HIP_CHECK(hipMemcpyAsync(&h, f->occupied, sizeof(h), hipMemcpyDeviceToHost, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+        *occupied = (int64_t)h;
+    }
+    return 0;
+}
+
+int bdmi_enable_timers(bdmi_flock *f, int enable) {
+    if (int rc = check(f)) return rc;
+    f->timers = enable != 0;
+    return 0;
+}
+
+int bdmi_get_timers(bdmi_flock *f, double *ms3, int64_t *count, int reset) {
+    if (int rc = check(f)) return rc;
+    if (ms3) memcpy(ms3, f->ms, sizeof(f->ms));
+    if (count) *count = f->timed;
+    if (reset) { memset(f->ms, 0, sizeof(f->ms)); f->timed = 0; }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,1128 @@
+// libnbmi.so - MI355X (gfx950) N-body backend: Barnes-Hut octree + stackless wave-shared tree
+// walk with fused kick-drift, and the LDS-tiled direct O(N^2) fallback.  C ABI in include/nbmi.h.
+//
+// Reference behaviour being reproduced (file:line in /root/reference):
+//   compute_bounds                nbody/simulation.py:308-317
+//   get_octant / _center          nbody/simulation.py:38-60      (key digits)
+//   build_octree                  nbody/simulation.py:63-198     (one body per leaf; cell SET is
+//                                                                  insertion-order independent)
+//   compute_forces_barnes_hut     nbody/simulation.py:201-278
+//   update_positions_velocities   nbody/simulation.py:281-305
+//   compute_colors_by_velocity    nbody/simulation.py:320-400
+//   compute_forces_*_cuda, update_bodies_cuda   nbody/gpu_backend.py:145-257
+//
+// Design (DESIGN.md has the full story):
+//   * master state float64 SoA in HBM, kept in key-sorted order (re-sorted every step; the
+//     permutation is nearly the identity so the gather is almost coalesced); `id` maps a
+//     sorted rank back to the caller's body index.
+//   * keys: per-body replay of the reference's compare/halve recurrence in float64, 42 levels
+//     (2 x 63 bit), so the cell set equals the reference's bit for bit.
+//   * tree: for key-sorted bodies, delta[r] = common octal prefix length of bodies r, r+1.
+//     Body r starts internal cells at levels (delta[r-1], delta[r]] and owns one leaf at level
+//     max(delta[r-1], delta[r]) + 1.  Nodes are emitted in DFS pre-order with a `next` (skip
+//     subtree) index, COM from float64 prefix sums of {m, m x} over the sorted bodies.
+//   * walk: one wave64 per 64 consecutive sorted bodies walks the pre-order array with a single
+//     wave-uniform cursor (scalar loads); every lane applies the reference's own per-body
+//     opening test; the wave descends if ANY lane opens, lanes that accepted an ancestor sit
+//     out until the cursor leaves that subtree.  Each lane's accepted set == the reference's.
+#include <stdarg.h>
+#include <stddef.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nbmi.h"
+#include "common.h"
+
+namespace nbmi {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+void clear_error() { g_err[0] = 0; }
+}  // namespace nbmi
+
+using nbmi::Moment;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxLevel = 42;  // key digits available (2 x 21)
+
+// 32-byte octree node, DFS pre-order.  Loaded with one scalar s_load_dwordx8 per visit.
+struct alignas(32) Node {
+    float cx, cy, cz;  // centre of mass (leaf: the body's position)
+    float gm;          // G * mass
+    float size2;       // (2*half_size)^2, 0 for leaves
+    int next;          // index of the first node after this node's subtree
+    int ref;           // leaf: sorted rank of its body (>= 0); internal: ~(rank of first body)
+    int level;         // depth, root = 0
+};
+static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
+
+struct Bodies {
+    double *x, *y, *z, *vx, *vy, *vz, *m;
+    int32_t *id;
+};
+
+struct TreeInfo {
+    unsigned long long maxabs_bits;  // max |coordinate| (non-negative double bit pattern)
+    double bounds;                   // root half size
+    long long num_nodes;             // N + number of internal cells (reference numbering)
+    int max_level;                   // deepest leaf level
+    int error;                       // 1 = node capacity exceeded
+    unsigned long long wave_visits, lane_visits, lane_accepts;
+};
+
+// ---------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// XCD-aware block remap: hardware deals consecutive blocks round-robin over the 8 XCDs, so give
+// XCD k a contiguous chunk of logical blocks (neighbouring body groups then share one L2).
+__device__ __forceinline__ int logical_block(int b, int nb) {
+    const int q = nb >> 3, rem = nb & 7;
+    const int xcd = b & 7, local = b >> 3;
+    return xcd * q + (xcd < rem ? xcd : rem) + local;
+}
+
+__device__ __forceinline__ int cpl_digits(uint64_t ahi, uint64_t alo, uint64_t bhi, uint64_t blo) {
+    const uint64_t xh = ahi ^ bhi;
+    if (xh) return (__clzll((long long)xh) - 1) / 3;
+    const uint64_t xl = alo ^ blo;
+    if (xl) return 21 + (__clzll((long long)xl) - 1) / 3;
+    return kMaxLevel;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: max |coordinate|  (compute_bounds, simulation.py:308-317; max is order independent)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_maxabs(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, int64_t n, TreeInfo *info) {
+    __shared__ double red[kBlock / 64];
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        mx = fmax(mx, fabs(x[i]));
+        mx = fmax(mx, fabs(y[i]));
+        mx = fmax(mx, fabs(z[i]));
+    }
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) mx = fmax(mx, red[w]);
+        atomicMax(&info->maxabs_bits, (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: octant-path keys.  Replays get_octant/get_octant_center (simulation.py:38-60) from the
+// root cube [-bounds, bounds]^3: digit = x>=cx | (y>=cy)<<1 | (z>=cz)<<2, centre +- hs/2.
+// Only compares, adds and exact halvings: bit-identical to the float64 reference.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, const double *__restrict__ y,
+                                                 const double *__restrict__ z, int64_t n, TreeInfo *info,
+                                                 uint64_t *__restrict__ key_hi, uint64_t *__restrict__ key_lo,
+                                                 uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    // bounds = max_extent * 1.1 + 10.0 with two roundings (no FMA contraction)
+    const double maxabs = __longlong_as_double((long long)info->maxabs_bits);
+    const double bounds = __dadd_rn(__dmul_rn(maxabs, 1.1), 10.0);
+    if (i == 0) info->bounds = bounds;
+    if (i >= n) return;
+    const double px = x[i], py = y[i], pz = z[i];
+    double cx = 0.0, cy = 0.0, cz = 0.0, hs = bounds;
+    uint64_t k[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        uint64_t kk = 0;
+        for (int l = 0; l < 21; l++) {
+            const double q = hs * 0.5;
+            const bool bx = px >= cx, by = py >= cy, bz = pz >= cz;
+            cx = bx ? cx + q : cx - q;
+            cy = by ? cy + q : cy - q;
+            cz = bz ? cz + q : cz - q;
+            hs = q;
+            kk = (kk << 3) | (uint64_t)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));
+        }
+        k[w] = kk;
+    }
+    key_hi[i] = k[0];
+    key_lo[i] = k[1];
+    idx[i] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: order runs of equal key_hi by key_lo (bodies that share all 21 upper digits; rare).
+// One thread per run start; insertion sort of the run's permutation entries.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
+                                                   uint32_t *__restrict__ perm, int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n - 1) return;
+    const uint64_t h = hi_s[r];
+    if (hi_s[r + 1] != h) return;
+    if (r > 0 && hi_s[r - 1] == h) return;  // not the run start
+    int64_t e = r + 2;
+    while (e < n && hi_s[e] == h) e++;
+    for (int64_t a = r + 1; a < e; a++) {
+        const uint32_t pa = perm[a];
+        const uint64_t la = key_lo[pa];
+        int64_t b = a - 1;
+        while (b >= r) {
+            const uint32_t pb = perm[b];
+            const uint64_t lb = key_lo[pb];
+            if (lb < la || (lb == la && pb < pa)) break;
+            perm[b + 1] = pb;
+            b--;
+        }
+        perm[b + 1] = pa;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K5: gather bodies into key order: fp32 {x,y,z,G*m} for the walk / leaves, low key word,
+// float64 moments {m, m x, m y, m z} for the COM prefix sums.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_gather(Bodies cur, const uint32_t *__restrict__ perm,
+                                                   const uint64_t *__restrict__ key_lo, int64_t n, double G,
+                                                   float4 *__restrict__ posm_s, uint64_t *__restrict__ lo_s,
+                                                   Moment *__restrict__ W) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r == 0) W[n] = Moment{0.0, 0.0, 0.0, 0.0};
+    if (r >= n) return;
+    const uint32_t j = perm[r];
+    const double px = cur.x[j], py = cur.y[j], pz = cur.z[j], m = cur.m[j];
+    posm_s[r] = make_float4((float)px, (float)py, (float)pz, (float)(G * m));
+    lo_s[r] = key_lo[j];
+    W[r] = Moment{m, m * px, m * py, m * pz};
+}
+
+// ---------------------------------------------------------------------------------------
+// K6: delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1);
+// cnt[r] = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
+                                                  int64_t n, int32_t *__restrict__ delta, int32_t *__restrict__ cnt) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r == 0) cnt[n] = 0;
+    if (r >= n) return;
+    const uint64_t h = hi_s[r], l = lo_s[r];
+    const int d = (r + 1 < n) ? cpl_digits(h, l, hi_s[r + 1], lo_s[r + 1]) : -1;
+    const int dp = (r > 0) ? cpl_digits(hi_s[r - 1], lo_s[r - 1], h, l) : -1;
+    delta[r] = d;
+    cnt[r] = d > dp ? d - dp : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K8: emit nodes in DFS pre-order.  Body r writes its internal cells (levels dp+1..d) at
+// r + Pex[r] + k and its leaf at r + Pex[r] + cnt.  The end of a cell is found by galloping +
+// binary search on the sorted keys.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
+                                                 const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
+                                                 const Moment *__restrict__ S, const float4 *__restrict__ posm_s,
+                                                 int64_t n, double G, int64_t capacity, Node *__restrict__ nodes,
+                                                 TreeInfo *info) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const double bounds = info->bounds;
+    const int d = delta[r];
+    const int dp = r > 0 ? delta[r - 1] : -1;
+    const int cnt = d > dp ? d - dp : 0;
+    const int64_t base = r + (int64_t)Pex[r];
+    if (r == 0) info->num_nodes = n + (long long)Pex[n];
+    if (base + cnt >= capacity) {
+        info->error = 1;
+        return;
+    }
+    const uint64_t h = hi_s[r], l = lo_s[r];
+    const Moment s0 = S[r];
+    for (int k = 0; k < cnt; k++) {
+        const int lev = dp + 1 + k;
+        // largest j with cpl(r, j) >= lev  (j = r qualifies); e = j + 1
+        int64_t ok = r, bad;
+        int64_t step = 1;
+        for (;;) {
+            const int64_t t = r + step;
+            if (t >= n) { bad = n; break; }
+            if (cpl_digits(h, l, hi_s[t], lo_s[t]) >= lev) { ok = t; step <<= 1; }
+            else { bad = t; break; }
+        }
+        while (bad - ok > 1) {
+            const int64_t mid = ok + ((bad - ok) >> 1);
+            if (cpl_digits(h, l, hi_s[mid], lo_s[mid]) >= lev) ok = mid; else bad = mid;
+        }
+        const int64_t e = bad;
+        const Moment s1 = S[e];
+        const double M = s1.m - s0.m;
+        double cx = 0.0, cy = 0.0, cz = 0.0;
+        if (M > 0.0) {
+            cx = (s1.x - s0.x) / M;
+            cy = (s1.y - s0.y) / M;
+            cz = (s1.z - s0.z) / M;
+        }
+        const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
+        Node nd;
+        nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
+        nd.gm = (float)(G * M);
+        nd.size2 = (float)(size * size);
+        nd.next = (int)(e + (int64_t)Pex[e]);
+        nd.ref = ~(int)r;
+        nd.level = lev;
+        nodes[base + k] = nd;
+    }
+    const float4 p = posm_s[r];
+    const int leaf_level = (d > dp ? d : dp) + 1;
+    Node lf;
+    lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
+    lf.size2 = 0.0f;
+    lf.next = (int)(base + cnt + 1);
+    lf.ref = (int)r;
+    lf.level = leaf_level;
+    nodes[base + cnt] = lf;
+    atomicMax(&info->max_level, leaf_level);
+}
+
+// ---------------------------------------------------------------------------------------
+// K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor `c` over the
+// pre-order node array; per lane the reference's test (simulation.py:245-274):
+//     skip own leaf; d = com - p; dist_sq = |d|^2 + eps^2;
+//     accept if leaf or (2 hs)^2 < theta^2 dist_sq      [== 2hs/dist < theta]
+//     accepted && mass>0 && dist_sq > eps^2  ->  a += G m d / dist^3
+// `resume` = first node index at which the lane takes part again (it accepted an ancestor of
+// everything before that).  The cursor moves to c+1 if any lane opens the node, else to
+// node.next.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
+// written at the body's NEW sorted rank (state re-ordering is fused into this kernel).
+// ---------------------------------------------------------------------------------------
+struct WalkParams {
+    int64_t n;
+    int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
+    float theta2, eps2;
+    double dt, damping;
+};
+
+template <bool kIntegrate, bool kCount>
+__global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const TreeInfo *info_in,
+                                                 const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
+                                                 Bodies cur, Bodies nxt, double *__restrict__ acc_out, WalkParams P,
+                                                 TreeInfo *info_out) {
+    const int lb = logical_block(blockIdx.x, gridDim.x);
+    const int64_t rank = P.rank_begin + (int64_t)lb * kBlock + threadIdx.x;
+    const bool valid = rank < P.rank_end;
+    const int nn = (info_in->error != 0) ? 0 : (int)info_in->num_nodes;
+
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+        const float4 p = posm_s[rank];
+        px = p.x; py = p.y; pz = p.z;
+    }
+    const int myrank = valid ? (int)rank : -2;
+    int resume = valid ? 0 : 0x7fffffff;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned long long wv = 0, lv = 0, la = 0;
+
+    int c = 0;
+    while (c < nn) {
+        c = __builtin_amdgcn_readfirstlane(c);
+        const Node nd = nodes[c];
+        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        const float dist_sq = d2 + P.eps2;
+        const bool active = resume <= c;
+        const bool leaf = nd.ref >= 0;
+        const bool geom = leaf || (nd.size2 < P.theta2 * dist_sq);
+        const bool take = active && geom;
+        const bool open = active && !geom;
+        const bool force = take && (nd.ref != myrank) && (d2 > 0.f);
+        const float inv = __builtin_amdgcn_rsqf(dist_sq);
+        const float f = force ? nd.gm * inv * inv * inv : 0.f;
+        ax = fmaf(dx, f, ax);
+        ay = fmaf(dy, f, ay);
+        az = fmaf(dz, f, az);
+        if (take) resume = nd.next;
+        const unsigned long long any_open = __ballot(open);
+        if (kCount) {
+            wv += 1;
+            lv += active ? 1 : 0;
+            la += force ? 1 : 0;
+        }
+        const int nxt_c = nd.next > c ? nd.next : c + 1;
+        c = any_open ? c + 1 : nxt_c;
+    }
+
+    if (kCount) {
+        // wave_visits counted once per wave (lane 0), lane counters summed over lanes
+        if ((threadIdx.x & 63) == 0) atomicAdd(&info_out->wave_visits, wv);
+        atomicAdd(&info_out->lane_visits, lv);
+        atomicAdd(&info_out->lane_accepts, la);
+    }
+    if (!valid) return;
+    const uint32_t j = perm[rank];
+    if (kIntegrate) {
+        double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
+        vx *= P.damping; vy *= P.damping; vz *= P.damping;
+        nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
+        nxt.x[rank] = cur.x[j] + vx * P.dt;
+        nxt.y[rank] = cur.y[j] + vy * P.dt;
+        nxt.z[rank] = cur.z[j] + vz * P.dt;
+        nxt.m[rank] = cur.m[j];
+        nxt.id[rank] = cur.id[j];
+    } else {
+        const int64_t o = 3 * (int64_t)cur.id[j];
+        acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct O(N^2): a_i = sum_{j != i} G m_j d (|d|^2 + eps^2)^(-3/2)   (gpu_backend.py:145-240)
+// 256-thread blocks, IB bodies per thread, 256-body tiles of {x,y,z,G m} staged in LDS and read
+// back as wave-uniform broadcasts.  fp32 pair arithmetic, per-tile fp32 partial sums folded
+// into float64 accumulators.  The j == i term is exactly zero when eps > 0 (d = 0); with
+// kGuard (eps == 0) pairs at zero distance are skipped.  Fused update_bodies_cuda
+// (gpu_backend.py:243-257): v = (v + a dt) * damping; x += v dt, new positions go to `nxt`.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_posm(Bodies cur, int64_t n, double G, float4 *__restrict__ posm) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    posm[i] = make_float4((float)cur.x[i], (float)cur.y[i], (float)cur.z[i], (float)(G * cur.m[i]));
+}
+
+template <int IB, bool kGuard, bool kIntegrate>
+__global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ posm, int64_t n, float eps2, Bodies cur,
+                                                   Bodies nxt, double *__restrict__ acc_out, double dt,
+                                                   double damping) {
+    __shared__ float4 tile[kBlock];
+    const int64_t i0 = (int64_t)blockIdx.x * (kBlock * IB) + threadIdx.x;
+    float px[IB], py[IB], pz[IB];
+    double ax[IB], ay[IB], az[IB];
+#pragma unroll
+    for (int k = 0; k < IB; k++) {
+        const int64_t i = i0 + (int64_t)k * kBlock;
+        const float4 p = i < n ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+        ax[k] = ay[k] = az[k] = 0.0;
+    }
+    const int64_t ntiles = (n + kBlock - 1) / kBlock;
+    for (int64_t t = 0; t < ntiles; t++) {
+        const int64_t j = t * kBlock + threadIdx.x;
+        tile[threadIdx.x] = j < n ? posm[j] : make_float4(0.f, 0.f, 0.f, 0.f);  // zero mass pads
+        __syncthreads();
+        float sx[IB], sy[IB], sz[IB];
+#pragma unroll
+        for (int k = 0; k < IB; k++) sx[k] = sy[k] = sz[k] = 0.f;
+#pragma unroll 8
+        for (int jj = 0; jj < kBlock; jj++) {
+            const float4 q = tile[jj];
+#pragma unroll
+            for (int k = 0; k < IB; k++) {
+                const float dx = q.x - px[k], dy = q.y - py[k], dz = q.z - pz[k];
+                const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
+                const float inv = __builtin_amdgcn_rsqf(r2);
+                float f = q.w * inv * inv * inv;
+                if (kGuard) f = (r2 > 0.f) ? f : 0.f;
+                sx[k] = fmaf(f, dx, sx[k]);
+                sy[k] = fmaf(f, dy, sy[k]);
+                sz[k] = fmaf(f, dz, sz[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IB; k++) {
+            ax[k] += (double)sx[k]; ay[k] += (double)sy[k]; az[k] += (double)sz[k];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < IB; k++) {
+        const int64_t i = i0 + (int64_t)k * kBlock;
+        if (i >= n) continue;
+        if (kIntegrate) {
+            const double vx = (cur.vx[i] + ax[k] * dt) * damping;
+            const double vy = (cur.vy[i] + ay[k] * dt) * damping;
+            const double vz = (cur.vz[i] + az[k] * dt) * damping;
+            nxt.vx[i] = vx; nxt.vy[i] = vy; nxt.vz[i] = vz;
+            nxt.x[i] = cur.x[i] + vx * dt;
+            nxt.y[i] = cur.y[i] + vy * dt;
+            nxt.z[i] = cur.z[i] + vz * dt;
+            nxt.m[i] = cur.m[i];
+            nxt.id[i] = cur.id[i];
+        } else {
+            const int64_t o = 3 * (int64_t)cur.id[i];
+            acc_out[o] = ax[k]; acc_out[o + 1] = ay[k]; acc_out[o + 2] = az[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// colour ramp (simulation.py:320-400 == gpu_backend.py:259-325), float64 maths, f32 stores,
+// rows written in the caller's body order.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_colors(Bodies cur, int64_t n, double max_speed, float *__restrict__ colors) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const double vx = cur.vx[r], vy = cur.vy[r], vz = cur.vz[r];
+    const double speed = sqrt(__dadd_rn(__dadd_rn(__dmul_rn(vx, vx), __dmul_rn(vy, vy)), __dmul_rn(vz, vz)));
+    double t = speed / max_speed;
+    t = t > 1.0 ? 1.0 : t;
+    double cr, cg, cb, s, s2;
+    if (t < 0.55) {
+        if (t < 0.15) {
+            s = t / 0.15;
+            cr = __dsub_rn(0.4, __dmul_rn(0.2, s)); cg = __dadd_rn(0.2, __dmul_rn(0.2, s)); cb = __dadd_rn(0.8, __dmul_rn(0.1, s));
+        } else if (t < 0.30) {
+            s = (t - 0.15) / 0.15;
+            cr = __dadd_rn(0.2, __dmul_rn(0.1, s)); cg = __dadd_rn(0.4, __dmul_rn(0.1, s)); cb = __dadd_rn(0.9, __dmul_rn(0.05, s));
+        } else {
+            s = (t - 0.30) / 0.25;
+            if (s < 0.6) {
+                s2 = s / 0.6;
+                cr = __dsub_rn(0.3, __dmul_rn(0.1, s2)); cg = __dadd_rn(0.5, __dmul_rn(0.3, s2)); cb = __dadd_rn(0.95, __dmul_rn(0.05, s2));
+            } else {
+                s2 = (s - 0.6) / 0.4;
+                cr = __dadd_rn(0.2, __dmul_rn(0.8, s2)); cg = __dadd_rn(0.8, __dmul_rn(0.2, s2)); cb = 1.0;
+            }
+        }
+    } else if (t < 0.90) {
+        cr = 1.0; cg = 1.0; cb = 1.0;
+    } else if (t < 0.95) {
+        s = (t - 0.90) / 0.05;
+        cr = 1.0; cg = __dsub_rn(1.0, __dmul_rn(0.05, s)); cb = __dsub_rn(1.0, __dmul_rn(1.0, s));
+    } else if (t < 0.99) {
+        s = (t - 0.95) / 0.04;
+        cr = 1.0; cg = __dsub_rn(0.95, __dmul_rn(0.45, s)); cb = 0.0;
+    } else {
+        s = (t - 0.99) / 0.01;
+        cr = 1.0; cg = __dsub_rn(0.5, __dmul_rn(0.5, s)); cb = 0.0;
+    }
+    const int64_t o = 3 * (int64_t)cur.id[r];
+    colors[o] = (float)cr; colors[o + 1] = (float)cg; colors[o + 2] = (float)cb;
+}
+
+// ---- un-permuting getters ------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_unperm3_f32(const double *__restrict__ a, const double *__restrict__ b,
+                                                        const double *__restrict__ c, const int32_t *__restrict__ id,
+                                                        int64_t n, float *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t o = 3 * (int64_t)id[r];
+    out[o] = (float)a[r]; out[o + 1] = (float)b[r]; out[o + 2] = (float)c[r];
+}
+__global__ __launch_bounds__(kBlock) void k_unperm3_f64(const double *__restrict__ a, const double *__restrict__ b,
+                                                        const double *__restrict__ c, const int32_t *__restrict__ id,
+                                                        int64_t n, double *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t o = 3 * (int64_t)id[r];
+    out[o] = a[r]; out[o + 1] = b[r]; out[o + 2] = c[r];
+}
+__global__ __launch_bounds__(kBlock) void k_split_state(const double *__restrict__ pos, const double *__restrict__ vel,
+                                                        const double *__restrict__ mass, Bodies cur, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    cur.x[i] = pos[3 * i]; cur.y[i] = pos[3 * i + 1]; cur.z[i] = pos[3 * i + 2];
+    cur.vx[i] = vel[3 * i]; cur.vy[i] = vel[3 * i + 1]; cur.vz[i] = vel[3 * i + 2];
+    if (mass) cur.m[i] = mass[i];
+    cur.id[i] = (int32_t)i;
+}
+// like k_split_state but keeps the current ordering: row of body id[r] goes to rank r
+__global__ __launch_bounds__(kBlock) void k_set_state_perm(const double *__restrict__ pos, const double *__restrict__ vel,
+                                                           Bodies cur, int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t i = cur.id[r];
+    cur.x[r] = pos[3 * i]; cur.y[r] = pos[3 * i + 1]; cur.z[r] = pos[3 * i + 2];
+    cur.vx[r] = vel[3 * i]; cur.vy[r] = vel[3 * i + 1]; cur.vz[r] = vel[3 * i + 2];
+}
+__global__ __launch_bounds__(kBlock) void k_keys_to_orig(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
+                                                         const uint32_t *__restrict__ perm, const int32_t *__restrict__ id,
+                                                         int64_t n, uint64_t *__restrict__ out_hi, uint64_t *__restrict__ out_lo) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const int64_t o = id[perm[r]];
+    out_hi[o] = hi_s[r];
+    out_lo[o] = lo_s[r];
+}
+__global__ __launch_bounds__(kBlock) void k_cells(const Node *__restrict__ nodes, const uint64_t *__restrict__ hi_s,
+                                                  int64_t num_nodes, int32_t *__restrict__ level, uint64_t *__restrict__ key) {
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (u >= num_nodes) return;
+    const Node nd = nodes[u];
+    const int r = nd.ref >= 0 ? nd.ref : ~nd.ref;
+    level[u] = nd.level;
+    key[u] = nd.level <= 21 ? (nd.level == 0 ? 0ull : (hi_s[r] >> (63 - 3 * nd.level))) : ~0ull;
+}
+// multi-GPU row pack / unpack: {x,y,z,vx,vy,vz,m,id}
+__global__ __launch_bounds__(kBlock) void k_pack_rows(Bodies cur, int64_t begin, int64_t end, double *__restrict__ rows) {
+    const int64_t r = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= end) return;
+    double *o = rows + 8 * (r - begin);
+    o[0] = cur.x[r]; o[1] = cur.y[r]; o[2] = cur.z[r];
+    o[3] = cur.vx[r]; o[4] = cur.vy[r]; o[5] = cur.vz[r];
+    o[6] = cur.m[r]; o[7] = (double)cur.id[r];
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_rows(Bodies cur, int64_t begin, int64_t end, const double *__restrict__ rows) {
+    const int64_t r = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= end) return;
+    const double *o = rows + 8 * (r - begin);
+    cur.x[r] = o[0]; cur.y[r] = o[1]; cur.z[r] = o[2];
+    cur.vx[r] = o[3]; cur.vy[r] = o[4]; cur.vz[r] = o[5];
+    cur.m[r] = o[6]; cur.id[r] = (int32_t)o[7];
+}
+
+inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+// =========================================================================================
+// handle
+// =========================================================================================
+struct nbmi_sim {
+    int64_t n = 0;
+    int method = 0, device = 0;
+    double G = 0, softening = 0, damping = 1, theta = 0.5;
+    hipStream_t stream = nullptr;
+    int curbuf = 0;
+    Bodies buf[2] = {};
+    // scratch
+    uint64_t *key_hi = nullptr, *key_lo = nullptr, *hi_s = nullptr, *lo_s = nullptr;
+    uint32_t *idx = nullptr, *perm = nullptr;
+    int32_t *delta = nullptr, *cnt = nullptr, *Pex = nullptr;
+    float4 *posm_s = nullptr;
+    Moment *W = nullptr, *S = nullptr;
+    Node *nodes = nullptr;
+    int64_t node_capacity = 0;
+    TreeInfo *info = nullptr;  // device
+    void *tmp_sort = nullptr, *tmp_scan_i = nullptr, *tmp_scan_m = nullptr;
+    size_t tmp_sort_bytes = 0, tmp_scan_i_bytes = 0, tmp_scan_m_bytes = 0;
+    float *colors = nullptr;  // (N,3) original order
+    void *stage = nullptr;    // getter staging, 3N doubles
+    bool tree_valid = false;
+    int64_t shard_begin = 0, shard_end = 0;
+    bool count_walk = false;
+    // timers
+    bool timers = false;
+    hipEvent_t ev[6] = {};
+    double ms[5] = {0, 0, 0, 0, 0};
+    int64_t timed_steps = 0;
+    std::vector<void *> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(nbmi_sim *s, T **p, size_t count) {
+    void *q = nullptr;
+    NBMI_HIP_CHECK(hipMalloc(&q, (count ? count : 1) * sizeof(T)));
+    s->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+
+int alloc_bodies(nbmi_sim *s, Bodies *b, int64_t n) {
+    if (dev_alloc(s, &b->x, n) || dev_alloc(s, &b->y, n) || dev_alloc(s, &b->z, n) || dev_alloc(s, &b->vx, n) ||
+        dev_alloc(s, &b->vy, n) || dev_alloc(s, &b->vz, n) || dev_alloc(s, &b->m, n) || dev_alloc(s, &b->id, n))
+        return -2;
+    return 0;
+}
+
+int check_handle(nbmi_sim *s) {
+    if (!s) {
+        nbmi::set_error("null nbmi_sim handle");
+        return NBMI_ERR_ARG;
+    }
+    if (hipSetDevice(s->device) != hipSuccess) {
+        nbmi::set_error("hipSetDevice(%d) failed", s->device);
+        return NBMI_ERR_HIP;
+    }
+    return 0;
+}
+
+// Enqueue bounds -> keys -> sort -> tie fix -> gather -> delta -> scans -> node emission.
+int enqueue_tree(nbmi_sim *s, int ev_base) {
+    const int64_t n = s->n;
+    hipStream_t st = s->stream;
+    Bodies cur = s->buf[s->curbuf];
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], st));
+    // reset maxabs/num_nodes/max_level/error (keep counters)
+    NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
+    int gb = nblocks(n);
+    if (gb > 2048) gb = 2048;
+    k_maxabs<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info);
+    k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
+    NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
+                                            (size_t)n, 0, 63, st));
+    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, n);
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
+    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s, s->W);
+    k_delta<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, n, s->delta, s->cnt);
+    NBMI_HIP_CHECK(nbmi::exclusive_scan_i32(s->tmp_scan_i, s->tmp_scan_i_bytes, s->cnt, s->Pex, (size_t)n + 1, st));
+    NBMI_HIP_CHECK(nbmi::exclusive_scan_moment(s->tmp_scan_m, s->tmp_scan_m_bytes, s->W, s->S, (size_t)n + 1, st));
+    k_emit<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->delta, s->Pex, s->S, s->posm_s, n, s->G,
+                                          s->node_capacity, s->nodes, s->info);
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], st));
+    NBMI_HIP_CHECK(hipGetLastError());
+    s->tree_valid = true;
+    return 0;
+}
+
+int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
+    const int64_t n = s->n;
+    hipStream_t st = s->stream;
+    Bodies cur = s->buf[s->curbuf], nxt = s->buf[1 - s->curbuf];
+    WalkParams P;
+    P.n = n;
+    P.rank_begin = integrate ? s->shard_begin : 0;
+    P.rank_end = integrate ? s->shard_end : n;
+    P.theta2 = (float)(s->theta * s->theta);
+    P.eps2 = (float)(s->softening * s->softening);
+    P.dt = dt;
+    P.damping = s->damping;
+    const int64_t cntr = P.rank_end - P.rank_begin;
+    if (cntr <= 0) return 0;
+    const int gb = nblocks(cntr);
+    if (integrate) {
+        if (s->count_walk)
+            k_walk<true, true><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, nullptr, P, s->info);
+        else
+            k_walk<true, false><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, nullptr, P, s->info);
+    } else {
+        k_walk<false, true><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info);
+    }
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <bool kIntegrate>
+int launch_direct(nbmi_sim *s, double dt, double *acc_out) {
+    const int64_t n = s->n;
+    hipStream_t st = s->stream;
+    Bodies cur = s->buf[s->curbuf], nxt = s->buf[1 - s->curbuf];
+    k_pack_posm<<<nblocks(n), kBlock, 0, st>>>(cur, n, s->G, s->posm_s);
+    const float eps2 = (float)(s->softening * s->softening);
+    const bool guard = !(eps2 > 0.f);
+    // bodies per thread: enough blocks to cover 256 CUs a few times over
+    int ib = n >= 512 * 1024 ? 4 : (n >= 128 * 1024 ? 2 : 1);
+#define NBMI_DIRECT(IBV)                                                                                      \
+    do {                                                                                                      \
+        const int gb = (int)((n + (int64_t)kBlock * IBV - 1) / ((int64_t)kBlock * IBV));                      \
+        if (guard)                                                                                            \
+            k_direct<IBV, true, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, eps2, cur, nxt, acc_out, dt, \
+                                                                  s->damping);                                \
+        else                                                                                                  \
+            k_direct<IBV, false, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, eps2, cur, nxt, acc_out, dt, \
+                                                                   s->damping);                               \
+    } while (0)
+    if (ib == 4) NBMI_DIRECT(4);
+    else if (ib == 2) NBMI_DIRECT(2);
+    else NBMI_DIRECT(1);
+#undef NBMI_DIRECT
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int check_device_error(nbmi_sim *s) {
+    TreeInfo h;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (h.error) {
+        nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference)",
+                        (long long)h.num_nodes, (long long)s->node_capacity);
+        return NBMI_ERR_CAPACITY;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int nbmi_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+const char *nbmi_last_error(void) { return nbmi::get_error(); }
+
+void nbmi_destroy(nbmi_sim *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (void *p : s->allocs) (void)hipFree(p);
+    for (auto &e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const double *mass) {
+    const int64_t n = s->n;
+    NBMI_HIP_CHECK(hipSetDevice(s->device));
+    NBMI_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (auto &e : s->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
+    if (alloc_bodies(s, &s->buf[0], n) || alloc_bodies(s, &s->buf[1], n)) return -2;
+    if (dev_alloc(s, &s->posm_s, n) || dev_alloc(s, &s->colors, 3 * n) || dev_alloc(s, &s->info, 1)) return -2;
+    void *stage = nullptr;
+    NBMI_HIP_CHECK(hipMalloc(&stage, (size_t)(n ? n : 1) * 7 * sizeof(double)));
+    s->allocs.push_back(stage);
+    s->stage = stage;
+    NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, sizeof(TreeInfo), s->stream));
+    NBMI_HIP_CHECK(hipMemsetAsync(s->colors, 0, (size_t)(n ? n : 1) * 3 * sizeof(float), s->stream));
+    if (s->method == NBMI_METHOD_BARNES_HUT) {
+        s->node_capacity = 4 * n + 4096;  // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N
+        if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
+            dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
+            dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
+            dev_alloc(s, &s->W, n + 1) || dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->nodes, s->node_capacity))
+            return -2;
+        s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
+        s->tmp_scan_i_bytes = nbmi::scan_i32_temp_bytes((size_t)n + 1);
+        s->tmp_scan_m_bytes = nbmi::scan_moment_temp_bytes((size_t)n + 1);
+        char *t = nullptr;
+        if (dev_alloc(s, &t, s->tmp_sort_bytes + 256)) return -2;
+        s->tmp_sort = t;
+        if (dev_alloc(s, &t, s->tmp_scan_i_bytes + 256)) return -2;
+        s->tmp_scan_i = t;
+        if (dev_alloc(s, &t, s->tmp_scan_m_bytes + 256)) return -2;
+        s->tmp_scan_m = t;
+    }
+    // upload AoS host arrays through the staging buffer and split to SoA
+    double *dpos = (double *)s->stage, *dvel = dpos + 3 * n, *dm = dvel + 3 * n;
+    if (n > 0) {
+        NBMI_HIP_CHECK(hipMemcpyAsync(dpos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        NBMI_HIP_CHECK(hipMemcpyAsync(dvel, vel, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        NBMI_HIP_CHECK(hipMemcpyAsync(dm, mass, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        k_split_state<<<nblocks(n), kBlock, 0, s->stream>>>(dpos, dvel, dm, s->buf[0], n);
+        NBMI_HIP_CHECK(hipGetLastError());
+    }
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->shard_begin = 0;
+    s->shard_end = n;
+    return 0;
+}
+
+nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const double *mass, double G,
+                      double softening, double damping, double theta, int method, int device) {
+    nbmi::clear_error();
+    if (n < 0 || n > 400000000 || (n > 0 && (!pos || !vel || !mass))) {
+        nbmi::set_error("nbmi_create: bad arguments (n=%lld)", (long long)n);
+        return nullptr;
+    }
+    if (method != NBMI_METHOD_BARNES_HUT && method != NBMI_METHOD_DIRECT) {
+        nbmi::set_error("nbmi_create: unknown method %d", method);
+        return nullptr;
+    }
+    if (!(softening >= 0.0) || !(theta >= 0.0)) {
+        nbmi::set_error("nbmi_create: softening and theta must be >= 0");
+        return nullptr;
+    }
+    int count = nbmi_device_count();
+    if (count <= 0) {
+        nbmi::set_error("nbmi_create: no HIP device available");
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        nbmi::set_error("nbmi_create: device %d out of range (have %d)", device, count);
+        return nullptr;
+    }
+    nbmi_sim *s = new nbmi_sim();
+    s->n = n; s->method = method; s->device = device;
+    s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
+    if (create_impl(s, pos, vel, mass) != 0) {
+        std::string keep = nbmi::get_error();
+        nbmi_destroy(s);
+        nbmi::set_error("%s", keep.c_str());
+        return nullptr;
+    }
+    return s;
+}
+
+int nbmi_step(nbmi_sim *s, double dt, int substeps) {
+    if (int rc = check_handle(s)) return rc;
+    if (substeps < 0) {
+        nbmi::set_error("nbmi_step: substeps < 0");
+        return NBMI_ERR_ARG;
+    }
+    if (s->n == 0) return 0;
+    for (int k = 0; k < substeps; k++) {
+        if (s->method == NBMI_METHOD_BARNES_HUT) {
+            const int evb = s->timers ? 0 : -1;
+            if (int rc = enqueue_tree(s, evb)) return rc;
+            if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
+            if (s->timers) {
+                NBMI_HIP_CHECK(hipEventRecord(s->ev[4], s->stream));
+                NBMI_HIP_CHECK(hipEventSynchronize(s->ev[4]));
+                for (int p = 0; p < 4; p++) {
+                    float ms = 0.f;
+                    NBMI_HIP_CHECK(hipEventElapsedTime(&ms, s->ev[p], s->ev[p + 1]));
+                    s->ms[p] += ms;
+                }
+                s->timed_steps++;
+            }
+            // a full (unsharded) step leaves every rank of the other buffer written
+            // (sharded handles: the ranks outside [shard_begin, shard_end) arrive via nbmi_import_ranks)
+            s->curbuf ^= 1;
+            s->tree_valid = false;
+        } else {
+            if (s->timers) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+            if (int rc = launch_direct<true>(s, dt, nullptr)) return rc;
+            if (s->timers) {
+                NBMI_HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+                NBMI_HIP_CHECK(hipEventSynchronize(s->ev[1]));
+                float ms = 0.f;
+                NBMI_HIP_CHECK(hipEventElapsedTime(&ms, s->ev[0], s->ev[1]));
+                s->ms[3] += ms;
+                s->timed_steps++;
+            }
+            s->curbuf ^= 1;
+        }
+    }
+    return 0;
+}
+
+int nbmi_compute_colors(nbmi_sim *s, double max_speed) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->n == 0) return 0;
+    k_colors<<<nblocks(s->n), kBlock, 0, s->stream>>>(s->buf[s->curbuf], s->n, max_speed, s->colors);
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int nbmi_sync(nbmi_sim *s) {
+    if (int rc = check_handle(s)) return rc;
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->method == NBMI_METHOD_BARNES_HUT) return check_device_error(s);
+    return 0;
+}
+
+static int get3(nbmi_sim *s, const double *a, const double *b, const double *c, void *out, bool f32) {
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    Bodies cur = s->buf[s->curbuf];
+    if (f32) k_unperm3_f32<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, cur.id, n, (float *)s->stage);
+    else k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, cur.id, n, (double *)s->stage);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(out, s->stage, (size_t)n * 3 * (f32 ? sizeof(float) : sizeof(double)),
+                                  hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->method == NBMI_METHOD_BARNES_HUT) return check_device_error(s);
+    return 0;
+}
+
+int nbmi_get_positions_f32(nbmi_sim *s, float *out) {
+    if (int rc = check_handle(s)) return rc;
+    if (!out && s->n) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    Bodies cur = s->buf[s->curbuf];
+    return get3(s, cur.x, cur.y, cur.z, out, true);
+}
+int nbmi_get_positions_f64(nbmi_sim *s, double *out) {
+    if (int rc = check_handle(s)) return rc;
+    if (!out && s->n) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    Bodies cur = s->buf[s->curbuf];
+    return get3(s, cur.x, cur.y, cur.z, out, false);
+}
+int nbmi_get_velocities_f64(nbmi_sim *s, double *out) {
+    if (int rc = check_handle(s)) return rc;
+    if (!out && s->n) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    Bodies cur = s->buf[s->curbuf];
+    return get3(s, cur.vx, cur.vy, cur.vz, out, false);
+}
+int nbmi_get_colors_f32(nbmi_sim *s, float *out) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->n == 0) return 0;
+    if (!out) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    NBMI_HIP_CHECK(hipMemcpyAsync(out, s->colors, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_set_state(nbmi_sim *s, const double *pos, const double *vel) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!pos || !vel) { nbmi::set_error("null input"); return NBMI_ERR_ARG; }
+    double *dpos = (double *)s->stage, *dvel = dpos + 3 * n;
+    NBMI_HIP_CHECK(hipMemcpyAsync(dpos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(dvel, vel, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    k_set_state_perm<<<nblocks(n), kBlock, 0, s->stream>>>(dpos, dvel, s->buf[s->curbuf], n);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->tree_valid = false;
+    return 0;
+}
+
+int nbmi_build_tree(nbmi_sim *s) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
+    if (s->n == 0) return 0;
+    if (int rc = enqueue_tree(s, -1)) return rc;
+    return check_device_error(s);
+}
+
+int nbmi_get_accelerations_f64(nbmi_sim *s, double *out) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!out) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    double *acc = (double *)s->stage;
+    if (s->method == NBMI_METHOD_BARNES_HUT) {
+        if (int rc = enqueue_tree(s, -1)) return rc;
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 3 * sizeof(unsigned long long), s->stream));
+        if (int rc = enqueue_walk(s, false, 0.0, acc)) return rc;
+    } else {
+        if (int rc = launch_direct<false>(s, 0.0, acc)) return rc;
+    }
+    NBMI_HIP_CHECK(hipMemcpyAsync(out, acc, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->method == NBMI_METHOD_BARNES_HUT) return check_device_error(s);
+    return 0;
+}
+
+int nbmi_tree_stats(nbmi_sim *s, int64_t *num_nodes, int32_t *max_depth, double *bounds) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
+    if (s->n == 0) {  // reference: empty root leaf, bounds = 0*1.1+10
+        if (num_nodes) *num_nodes = 1;
+        if (max_depth) *max_depth = 0;
+        if (bounds) *bounds = 10.0;
+        return 0;
+    }
+    TreeInfo h;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (num_nodes) *num_nodes = h.num_nodes;
+    if (max_depth) *max_depth = h.max_level;
+    if (bounds) *bounds = h.bounds;
+    if (h.error) {
+        nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated", (long long)h.num_nodes,
+                        (long long)s->node_capacity);
+        return NBMI_ERR_CAPACITY;
+    }
+    return 0;
+}
+
+int nbmi_get_keys(nbmi_sim *s, uint64_t *key_hi, uint64_t *key_lo) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT || !s->tree_valid) {
+        nbmi::set_error("nbmi_get_keys: call nbmi_build_tree first");
+        return NBMI_ERR_ARG;
+    }
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    uint64_t *o_hi = (uint64_t *)s->stage, *o_lo = o_hi + n;
+    k_keys_to_orig<<<nblocks(n), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->perm, s->buf[s->curbuf].id, n, o_hi, o_lo);
+    NBMI_HIP_CHECK(hipGetLastError());
+    if (key_hi) NBMI_HIP_CHECK(hipMemcpyAsync(key_hi, o_hi, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (key_lo) NBMI_HIP_CHECK(hipMemcpyAsync(key_lo, o_lo, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT || !s->tree_valid) {
+        nbmi::set_error("nbmi_get_cells: call nbmi_build_tree first");
+        return NBMI_ERR_ARG;
+    }
+    int64_t nn = 0;
+    if (int rc = nbmi_tree_stats(s, &nn, nullptr, nullptr)) return rc;
+    if (nn > capacity || !level || !key) {
+        nbmi::set_error("nbmi_get_cells: need room for %lld cells", (long long)nn);
+        return NBMI_ERR_ARG;
+    }
+    if (s->n == 0) { level[0] = 0; key[0] = 0; return 0; }
+    int32_t *dl = nullptr;
+    uint64_t *dk = nullptr;
+    NBMI_HIP_CHECK(hipMalloc((void **)&dl, (size_t)nn * 4));
+    NBMI_HIP_CHECK(hipMalloc((void **)&dk, (size_t)nn * 8));
+    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->hi_s, nn, dl, dk);
+    hipError_t e1 = hipMemcpyAsync(level, dl, (size_t)nn * 4, hipMemcpyDeviceToHost, s->stream);
+    hipError_t e2 = hipMemcpyAsync(key, dk, (size_t)nn * 8, hipMemcpyDeviceToHost, s->stream);
+    hipError_t e3 = hipStreamSynchronize(s->stream);
+    (void)hipFree(dl);
+    (void)hipFree(dk);
+    NBMI_HIP_CHECK(e1);
+    NBMI_HIP_CHECK(e2);
+    NBMI_HIP_CHECK(e3);
+    return 0;
+}
+
+int nbmi_enable_timers(nbmi_sim *s, int enable) {
+    if (int rc = check_handle(s)) return rc;
+    s->timers = enable != 0;
+    return 0;
+}
+
+int nbmi_get_timers(nbmi_sim *s, double *ms5, int64_t *count, int reset) {
+    if (int rc = check_handle(s)) return rc;
+    if (ms5) memcpy(ms5, s->ms, sizeof(s->ms));
+    if (count) *count = s->timed_steps;
+    if (reset) {
+        memset(s->ms, 0, sizeof(s->ms));
+        s->timed_steps = 0;
+    }
+    return 0;
+}
+
+int nbmi_walk_counters(nbmi_sim *s, int64_t *out3) {
+    if (int rc = check_handle(s)) return rc;
+    if (!out3) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    TreeInfo h;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    out3[0] = (int64_t)h.wave_visits; out3[1] = (int64_t)h.lane_visits; out3[2] = (int64_t)h.lane_accepts;
+    return 0;
+}
+
+int nbmi_set_shard(nbmi_sim *s, int64_t begin, int64_t end) {
+    if (int rc = check_handle(s)) return rc;
+    if (begin < 0 || end < begin || end > s->n) {
+        nbmi::set_error("nbmi_set_shard: bad range [%lld,%lld) for n=%lld", (long long)begin, (long long)end, (long long)s->n);
+        return NBMI_ERR_ARG;
+    }
+    s->shard_begin = begin;
+    s->shard_end = end;
+    return 0;
+}
+
+int nbmi_export_shard(nbmi_sim *s, void *dev_rows) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t c = s->shard_end - s->shard_begin;
+    if (c <= 0) return 0;
+    if (!dev_rows) { nbmi::set_error("null device buffer"); return NBMI_ERR_ARG; }
+    k_pack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], s->shard_begin, s->shard_end, (double *)dev_rows);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_import_ranks(nbmi_sim *s, const void *dev_rows, int64_t begin, int64_t end) {
+    if (int rc = check_handle(s)) return rc;
+    if (begin < 0 || end < begin || end > s->n) { nbmi::set_error("nbmi_import_ranks: bad range"); return NBMI_ERR_ARG; }
+    const int64_t c = end - begin;
+    if (c == 0) return 0;
+    if (!dev_rows) { nbmi::set_error("null device buffer"); return NBMI_ERR_ARG; }
+    k_unpack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], begin, end, (const double *)dev_rows);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->tree_valid = false;
+    return 0;
+}
+
+void *nbmi_stream(nbmi_sim *s) { return s ? (void *)s->stream : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""ctypes binding of libnbmi.so (C ABI declared in include/nbmi.h and include/bdmi.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at load time,
+and if no HIP device is present the constructors raise RuntimeError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbmi.so")
+
+_lib = None
+
+_i64 = C.c_int64
+_dbl = C.c_double
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/nbmi.h and include/bdmi.h
+PROTOTYPES = {
+    "nbmi_device_count": (C.c_int, []),
+    "nbmi_last_error": (C.c_char_p, []),
+    "nbmi_create": (_vp, [_i64, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.c_int, C.c_int]),
+    "nbmi_destroy": (None, [_vp]),
+    "nbmi_step": (C.c_int, [_vp, _dbl, C.c_int]),
+    "nbmi_compute_colors": (C.c_int, [_vp, _dbl]),
+    "nbmi_get_positions_f32": (C.c_int, [_vp, _vp]),
+    "nbmi_get_velocities_f64": (C.c_int, [_vp, _vp]),
+    "nbmi_get_colors_f32": (C.c_int, [_vp, _vp]),
+    "nbmi_sync": (C.c_int, [_vp]),
+    "nbmi_get_positions_f64": (C.c_int, [_vp, _vp]),
+    "nbmi_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "nbmi_build_tree": (C.c_int, [_vp]),
+    "nbmi_get_accelerations_f64": (C.c_int, [_vp, _vp]),
+    "nbmi_tree_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "nbmi_get_keys": (C.c_int, [_vp, _vp, _vp]),
+    "nbmi_get_cells": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "nbmi_enable_timers": (C.c_int, [_vp, C.c_int]),
+    "nbmi_get_timers": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "nbmi_walk_counters": (C.c_int, [_vp, _vp]),
+    "nbmi_set_shard": (C.c_int, [_vp, _i64, _i64]),
+    "nbmi_export_shard": (C.c_int, [_vp, _vp]),
+    "nbmi_import_ranks": (C.c_int, [_vp, _vp, _i64, _i64]),
+    "nbmi_stream": (_vp, [_vp]),
+    "bdmi_create": (_vp, [_i64, _vp, _vp, _vp, _vp, C.c_int]),
+    "bdmi_destroy": (None, [_vp]),
+    "bdmi_last_error": (C.c_char_p, []),
+    "bdmi_step": (C.c_int, [_vp, _dbl, C.c_int]),
+    "bdmi_sync": (C.c_int, [_vp]),
+    "bdmi_get_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "bdmi_set_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "bdmi_get_cell_indices": (C.c_int, [_vp, _vp]),
+    "bdmi_get_forces": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bdmi_grid_info": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "bdmi_enable_timers": (C.c_int, [_vp, C.c_int]),
+    "bdmi_get_timers": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+}
+
+
+def load():
+    """Load libnbmi.so (once).  Raises ImportError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C <package>/csrc`. "
+            "There is no CPU fallback in this package.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().nbmi_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def device_count():
+    return int(load().nbmi_device_count())
+
+
+def ptr(a):
+    """Data pointer of a C-contiguous NumPy array (or None)."""
+    return None if a is None else a.ctypes.data

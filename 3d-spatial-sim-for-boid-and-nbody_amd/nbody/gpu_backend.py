@@ -1,0 +1,260 @@
+"""Backend seam of the N-body simulation - MI355X / HIP edition.
+
+Mirrors the reference's nbody/gpu_backend.py: the ``Backend`` enum (:29-33) gains a ``HIP``
+member that ``detect_backend`` (:36-55) tries first; ``get_backend`` / ``force_backend``
+(:119-132) keep their cached-global behaviour; ``create_gpu_simulation`` (:623-679) returns an
+object speaking the reference's backend protocol
+
+    step(dt) / compute_colors(max_speed) / get_positions() -> (N,3) f32 /
+    get_velocities() -> (N,3) f64 / get_colors() -> (N,3) f32 / sync()
+
+(reference class CUDASimulation, :336-409) or ``None`` when no HIP device exists - the
+reference's own "fall back" convention.  This package has no CPU path to fall back to, so its
+callers (NBodySimulation, record) raise on ``None``.
+"""
+import ctypes as C
+import os
+from enum import Enum
+from typing import Optional, Tuple
+
+import numpy as np
+
+import nbmi_native as _nat
+
+METHOD_BARNES_HUT = 0
+METHOD_DIRECT = 1
+
+
+class Backend(Enum):
+    HIP = "hip"                    # MI355X: Barnes-Hut (default) or direct N^2 in hand-written HIP
+    CUDA = "cuda"                  # reference members kept so `Backend.X` comparisons still work
+    METAL_BH = "metal_barnes_hut"
+    METAL = "metal"
+    CPU = "cpu"
+
+
+def _check_hip() -> Tuple[bool, str]:
+    try:
+        n = _nat.device_count()
+    except (ImportError, OSError, AttributeError) as e:  # library missing / stale
+        return False, f"libnbmi.so unavailable: {e}"
+    if n > 0:
+        return True, f"{n} HIP device(s), gfx950 kernels (libnbmi.so)"
+    return False, "no HIP device"
+
+
+def detect_backend() -> Tuple[Backend, str]:
+    ok, info = _check_hip()
+    if ok:
+        return Backend.HIP, info
+    return Backend.CPU, info
+
+
+_BACKEND: Optional[Backend] = None
+_BACKEND_INFO: str = ""
+
+
+def get_backend() -> Tuple[Backend, str]:
+    """Current backend, detected once and cached (reference :119-125)."""
+    global _BACKEND, _BACKEND_INFO
+    if _BACKEND is None:
+        _BACKEND, _BACKEND_INFO = detect_backend()
+        print(f"[GPU] Using backend: {_BACKEND.value} - {_BACKEND_INFO}")
+    return _BACKEND, _BACKEND_INFO
+
+
+def force_backend(backend: Backend):
+    """Pin the backend (reference :128-132)."""
+    global _BACKEND, _BACKEND_INFO
+    _BACKEND = backend
+    _BACKEND_INFO = f"Forced: {backend.value}"
+
+
+def _as_f64(a, shape_tail):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape[1:] != shape_tail:
+        raise ValueError(f"expected array of shape (N,{','.join(map(str, shape_tail))}), got {a.shape}")
+    return a
+
+
+class _HIPSimulation:
+    """Shared implementation of the backend protocol on top of the nbmi_* C ABI."""
+
+    _method = METHOD_BARNES_HUT
+
+    def __init__(self, positions, velocities, masses, G, softening, damping, theta=0.5, device=None):
+        lib = _nat.load()
+        pos = _as_f64(positions, (3,))
+        vel = _as_f64(velocities, (3,))
+        m = _as_f64(masses, ())
+        if not (len(pos) == len(vel) == len(m)):
+            raise ValueError("positions, velocities and masses must have the same length")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, _nat.device_count())
+        self.n = len(pos)
+        self.G, self.softening, self.damping, self.theta = float(G), float(softening), float(damping), float(theta)
+        self.device = int(device)
+        self._lib = lib
+        self._h = lib.nbmi_create(self.n, _nat.ptr(pos), _nat.ptr(vel), _nat.ptr(m), self.G, self.softening,
+                                  self.damping, self.theta, self._method, self.device)
+        if not self._h:
+            raise RuntimeError(f"nbmi_create failed: {_nat.last_error()}")
+        kind = "Barnes-Hut" if self._method == METHOD_BARNES_HUT else "direct N^2"
+        print(f"[HIP] Initialized with {self.n:,} bodies ({kind}) on device {self.device}")
+
+    # ---- reference protocol -------------------------------------------------------------
+    def step(self, dt: float):
+        _nat.check(self._lib.nbmi_step(self._h, float(dt), 1), "nbmi_step")
+
+    def compute_colors(self, max_speed: float):
+        _nat.check(self._lib.nbmi_compute_colors(self._h, float(max_speed)), "nbmi_compute_colors")
+
+    def get_positions(self) -> np.ndarray:
+        out = np.empty((self.n, 3), dtype=np.float32)
+        _nat.check(self._lib.nbmi_get_positions_f32(self._h, _nat.ptr(out)), "nbmi_get_positions_f32")
+        return out
+
+    def get_velocities(self) -> np.ndarray:
+        out = np.empty((self.n, 3), dtype=np.float64)
+        _nat.check(self._lib.nbmi_get_velocities_f64(self._h, _nat.ptr(out)), "nbmi_get_velocities_f64")
+        return out
+
+    def get_colors(self) -> np.ndarray:
+        out = np.empty((self.n, 3), dtype=np.float32)
+        _nat.check(self._lib.nbmi_get_colors_f32(self._h, _nat.ptr(out)), "nbmi_get_colors_f32")
+        return out
+
+    def sync(self):
+        _nat.check(self._lib.nbmi_sync(self._h), "nbmi_sync")
+
+    # ---- supersets ----------------------------------------------------------------------
+    def step_many(self, dt: float, substeps: int):
+        """`substeps` steps enqueued back to back without host round trips."""
+        _nat.check(self._lib.nbmi_step(self._h, float(dt), int(substeps)), "nbmi_step")
+
+    def get_positions_f64(self) -> np.ndarray:
+        out = np.empty((self.n, 3), dtype=np.float64)
+        _nat.check(self._lib.nbmi_get_positions_f64(self._h, _nat.ptr(out)), "nbmi_get_positions_f64")
+        return out
+
+    def set_state(self, positions, velocities):
+        pos = _as_f64(positions, (3,))
+        vel = _as_f64(velocities, (3,))
+        if len(pos) != self.n or len(vel) != self.n:
+            raise ValueError("state arrays must have N rows")
+        _nat.check(self._lib.nbmi_set_state(self._h, _nat.ptr(pos), _nat.ptr(vel)), "nbmi_set_state")
+
+    def accelerations(self) -> np.ndarray:
+        """Accelerations of the current positions (force pass only, no integration)."""
+        out = np.empty((self.n, 3), dtype=np.float64)
+        _nat.check(self._lib.nbmi_get_accelerations_f64(self._h, _nat.ptr(out)), "nbmi_get_accelerations_f64")
+        return out
+
+    def enable_timers(self, on=True):
+        _nat.check(self._lib.nbmi_enable_timers(self._h, 1 if on else 0), "nbmi_enable_timers")
+
+    def timers(self, reset=False):
+        ms = np.zeros(5)
+        cnt = C.c_int64(0)
+        _nat.check(self._lib.nbmi_get_timers(self._h, _nat.ptr(ms), C.addressof(cnt), 1 if reset else 0),
+                   "nbmi_get_timers")
+        names = ("keys_ms", "sort_ms", "tree_ms", "walk_ms", "other_ms")
+        d = dict(zip(names, ms.tolist()))
+        d["steps"] = int(cnt.value)
+        return d
+
+    def stream_handle(self) -> int:
+        return int(self._lib.nbmi_stream(self._h) or 0)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nbmi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HIPBarnesHutSimulation(_HIPSimulation):
+    """Octree build + tree walk + kick-drift on the GPU (reference CPU path
+    nbody/simulation.py:63-305 behind the protocol of MetalBarnesHutSimulation,
+    nbody/metal/metal_backend.py:246)."""
+
+    _method = METHOD_BARNES_HUT
+
+    def build_tree(self):
+        _nat.check(self._lib.nbmi_build_tree(self._h), "nbmi_build_tree")
+
+    def tree_stats(self):
+        """num_nodes as build_octree returns it, max depth, root half size (compute_bounds)."""
+        nn, md, b = C.c_int64(0), C.c_int32(0), C.c_double(0)
+        _nat.check(self._lib.nbmi_tree_stats(self._h, C.addressof(nn), C.addressof(md), C.addressof(b)),
+                   "nbmi_tree_stats")
+        return dict(num_nodes=int(nn.value), max_depth=int(md.value), bounds=float(b.value))
+
+    def morton_keys(self):
+        """(key_hi, key_lo) uint64 per body, caller's order, for the last built tree."""
+        hi = np.empty(self.n, dtype=np.uint64)
+        lo = np.empty(self.n, dtype=np.uint64)
+        _nat.check(self._lib.nbmi_get_keys(self._h, _nat.ptr(hi), _nat.ptr(lo)), "nbmi_get_keys")
+        return hi, lo
+
+    def cells(self):
+        """(level, key) of every node of the last built tree."""
+        nn = self.tree_stats()["num_nodes"]
+        level = np.empty(nn, dtype=np.int32)
+        key = np.empty(nn, dtype=np.uint64)
+        _nat.check(self._lib.nbmi_get_cells(self._h, _nat.ptr(level), _nat.ptr(key), nn), "nbmi_get_cells")
+        return level, key
+
+    def walk_counters(self):
+        out = np.zeros(3, dtype=np.int64)
+        _nat.check(self._lib.nbmi_walk_counters(self._h, _nat.ptr(out)), "nbmi_walk_counters")
+        return dict(wave_visits=int(out[0]), lane_visits=int(out[1]), lane_accepts=int(out[2]))
+
+    # multi-GPU hooks (device pointers; see nbody/sharded.py)
+    def set_shard(self, begin, end):
+        _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")
+
+    def export_shard(self, dev_ptr):
+        _nat.check(self._lib.nbmi_export_shard(self._h, int(dev_ptr)), "nbmi_export_shard")
+
+    def import_ranks(self, dev_ptr, begin, end):
+        _nat.check(self._lib.nbmi_import_ranks(self._h, int(dev_ptr), int(begin), int(end)), "nbmi_import_ranks")
+
+
+class HIPDirectSimulation(_HIPSimulation):
+    """All-pairs O(N^2) forces, LDS tiled (reference CUDASimulation, nbody/gpu_backend.py:336-409;
+    no theta)."""
+
+    _method = METHOD_DIRECT
+
+    def __init__(self, positions, velocities, masses, G, softening, damping, device=None):
+        super().__init__(positions, velocities, masses, G, softening, damping, theta=0.0, device=device)
+
+
+# Reference thresholds (:618-620) exist because its GPU paths are O(N^2); the HIP Barnes-Hut
+# backend is O(N log N) like the reference's Metal one, so it takes every size.
+HIP_BH_THRESHOLD = 400_000_000
+
+
+def create_gpu_simulation(positions: np.ndarray, velocities: np.ndarray, masses: np.ndarray, G: float,
+                          softening: float, damping: float, theta: float = 0.5, force_gpu: bool = False,
+                          method: Optional[str] = None):
+    """Reference signature (:623-625) plus ``method`` ("barnes_hut" default, or "direct").
+
+    Returns a backend object, or None if the HIP backend is not available / not selected."""
+    backend, _info = get_backend()
+    n = len(positions)
+    if backend != Backend.HIP:
+        return None
+    method = method or os.environ.get("NBMI_METHOD", "barnes_hut")
+    if method == "direct":
+        return HIPDirectSimulation(positions, velocities, masses, G, softening, damping)
+    if n <= HIP_BH_THRESHOLD or force_gpu:
+        return HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta)
+    print(f"[GPU] {n:,} bodies exceeds the HIP Barnes-Hut limit ({HIP_BH_THRESHOLD:,})")
+    return None

@@ -1,0 +1,305 @@
+"""Offline recorder on the HIP backend: the reference's frame / state on-disk format
+(tools/record.py) and its record() GPU loop (:702-935, GPU branch :821-832).
+
+On-disk contract kept so the reference's playback can read the output:
+  recordings/<session>/metadata.json                     (:50-58)
+  frame_%04d.npz   = np.savez(positions=f32 (N,3), colors=f32 (N,3))          (:88-96)
+  frame_%04d.zstd  = u8 format (1 absolute | 2 delta) + u32 len + zstd(positions) +
+                     u32 len + zstd(colors); format 2 payload = int16((cur-prev)*1000)   (:231-326)
+  state_%04d.npz   = positions, velocities every 50 frames, previous one deleted   (:867-876)
+                     (+ `masses`, a superset key: the reference loses masses on resume [quirk])
+The interactive menus, progress bars and the background compressor thread are UX and are not
+reproduced; ``compress_recording`` converts finished .npz frames to .zstd in batches of 50 with
+the same delta chaining.  zstd comes from the system libzstd through ctypes (python-zstandard is
+not installed in this image); without it the .zstd functions raise and raw .npz still works.
+"""
+import ctypes as C
+import json
+import struct
+import time
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+
+PROJECT_ROOT = Path(__file__).resolve().parent.parent
+COMPRESSION_BATCH_SIZE = 50  # reference :225
+ZSTD_LEVEL = 19              # reference :252
+STATE_EVERY = 50             # reference :867
+
+
+# ---- zstd through ctypes ------------------------------------------------------------------
+_zstd = None
+
+
+def _load_zstd():
+    global _zstd
+    if _zstd is None:
+        for name in ("libzstd.so.1", "libzstd.so"):
+            try:
+                z = C.CDLL(name)
+                break
+            except OSError:
+                z = None
+        if z is None:
+            raise RuntimeError("libzstd not found: .zstd frames unavailable (raw .npz frames still work)")
+        z.ZSTD_compressBound.restype = C.c_size_t
+        z.ZSTD_compressBound.argtypes = [C.c_size_t]
+        z.ZSTD_compress.restype = C.c_size_t
+        z.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        z.ZSTD_decompress.restype = C.c_size_t
+        z.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        z.ZSTD_getFrameContentSize.restype = C.c_ulonglong
+        z.ZSTD_getFrameContentSize.argtypes = [C.c_void_p, C.c_size_t]
+        z.ZSTD_isError.restype = C.c_uint
+        z.ZSTD_isError.argtypes = [C.c_size_t]
+        _zstd = z
+    return _zstd
+
+
+def zstd_compress(data: bytes, level: int = ZSTD_LEVEL) -> bytes:
+    z = _load_zstd()
+    cap = z.ZSTD_compressBound(len(data))
+    dst = C.create_string_buffer(cap)
+    n = z.ZSTD_compress(dst, cap, data, len(data), level)
+    if z.ZSTD_isError(n):
+        raise RuntimeError("ZSTD_compress failed")
+    return dst.raw[:n]
+
+
+def zstd_decompress(data: bytes) -> bytes:
+    z = _load_zstd()
+    size = z.ZSTD_getFrameContentSize(data, len(data))
+    if size >= (1 << 62):
+        raise ValueError("zstd frame without content size")
+    dst = C.create_string_buffer(max(1, size))
+    n = z.ZSTD_decompress(dst, size, data, len(data))
+    if z.ZSTD_isError(n) or n != size:
+        raise ValueError("ZSTD_decompress failed")
+    return dst.raw[:size]
+
+
+# ---- session directory / metadata (reference :43-85) ----------------------------------------
+def get_recording_dir(session_name: str, root: Path = None) -> Path:
+    base = Path(root or PROJECT_ROOT) / "recordings" / session_name
+    base.mkdir(parents=True, exist_ok=True)
+    return base
+
+
+def save_metadata(rec_dir: Path, config: dict, start_time: float):
+    meta = {**config, "start_time": start_time, "start_datetime": datetime.fromtimestamp(start_time).isoformat()}
+    with open(Path(rec_dir) / "metadata.json", "w") as f:
+        json.dump(meta, f, indent=2)
+
+
+def load_metadata(rec_dir: Path) -> dict:
+    with open(Path(rec_dir) / "metadata.json", "r") as f:
+        return json.load(f)
+
+
+def _frame_paths(rec_dir, idx):
+    rec_dir = Path(rec_dir)
+    return rec_dir / f"frame_{idx:04d}.zstd", rec_dir / f"frame_{idx:04d}.npz"
+
+
+def get_completed_frames(rec_dir: Path) -> int:
+    """Number of contiguous frames from 0 present as .npz or .zstd (reference :67-76)."""
+    count = 0
+    while any(p.exists() for p in _frame_paths(rec_dir, count)):
+        count += 1
+    return count
+
+
+def find_latest_state(rec_dir: Path, max_frame: int):
+    for frame in range(max_frame, -1, -1):
+        p = Path(rec_dir) / f"state_{frame:04d}.npz"
+        if p.exists():
+            return p, frame
+    return None, -1
+
+
+# ---- frames (reference :88-210, :231-326) -----------------------------------------------------
+def save_frame(rec_dir: Path, frame_idx: int, positions: np.ndarray, colors: np.ndarray):
+    np.savez(Path(rec_dir) / f"frame_{frame_idx:04d}.npz", positions=positions.astype(np.float32),
+             colors=colors.astype(np.float32))
+
+
+def delta_quantize(cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
+    """int16((cur - prev) * 1000) with the reference's C-cast wrap-around beyond +-32.767
+    (reference :254-262 [quirk]: lossy, wraps)."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        return ((cur - prev) * 1000).astype(np.int16)
+
+
+def compress_frame(positions, colors, prev_positions=None, prev_colors=None) -> bytes:
+    use_delta = prev_positions is not None and prev_colors is not None
+    if use_delta:
+        pos_data = delta_quantize(positions, prev_positions).tobytes()
+        col_data = delta_quantize(colors, prev_colors).tobytes()
+    else:
+        pos_data = positions.astype(np.float32).tobytes()
+        col_data = colors.astype(np.float32).tobytes()
+    pc, cc = zstd_compress(pos_data), zstd_compress(col_data)
+    return struct.pack("B", 2 if use_delta else 1) + struct.pack("I", len(pc)) + pc + struct.pack("I", len(cc)) + cc
+
+
+def _split_container(data: bytes):
+    if len(data) < 1:
+        raise ValueError("Invalid compressed data")
+    fmt = data[0]
+    off = 1
+    (psz,) = struct.unpack("I", data[off:off + 4])
+    off += 4
+    pbytes = data[off:off + psz]
+    off += psz
+    (csz,) = struct.unpack("I", data[off:off + 4])
+    off += 4
+    return fmt, pbytes, data[off:off + csz]
+
+
+def decompress_frame(data: bytes, prev_positions=None, prev_colors=None):
+    fmt, pbytes, cbytes = _split_container(data)
+    pos_data, col_data = zstd_decompress(pbytes), zstd_decompress(cbytes)
+    if fmt == 1:
+        return (np.frombuffer(pos_data, dtype=np.float32).reshape(-1, 3),
+                np.frombuffer(col_data, dtype=np.float32).reshape(-1, 3))
+    if fmt == 2:
+        if prev_positions is None or prev_colors is None:
+            raise ValueError("Delta compression requires previous frame")
+        dp = np.frombuffer(pos_data, dtype=np.int16).reshape(-1, 3).astype(np.float32) / 1000.0
+        dc = np.frombuffer(col_data, dtype=np.int16).reshape(-1, 3).astype(np.float32) / 1000.0
+        return prev_positions + dp, prev_colors + dc
+    raise ValueError(f"Unknown compression format: {fmt}")
+
+
+def load_frame(rec_dir: Path, frame_idx: int, prev_positions=None, prev_colors=None):
+    """(positions f32 (N,3), colors f32 (N,3)); delta frames are resolved by walking back to the
+    nearest absolute (.zstd format 1) or raw .npz frame, iteratively (reference :99-210)."""
+    zf, nf = _frame_paths(rec_dir, frame_idx)
+    if zf.exists():
+        data = zf.read_bytes()
+        if data and data[0] == 2 and (prev_positions is None or prev_colors is None):
+            if frame_idx == 0:
+                raise ValueError(f"Frame {frame_idx:04d} appears to be delta-compressed but is the first frame")
+            chain = []
+            k = frame_idx - 1
+            base = None
+            while k >= 0:
+                zk, nk = _frame_paths(rec_dir, k)
+                if zk.exists():
+                    dk = zk.read_bytes()
+                    chain.append(dk)
+                    if dk[0] == 1:
+                        break
+                elif nk.exists():
+                    with np.load(nk) as d:
+                        base = (d["positions"].copy(), d["colors"].copy())
+                    break
+                else:
+                    raise FileNotFoundError(f"Frame {k:04d} not found (needed for delta decompression)")
+                k -= 1
+            if base is None:
+                if not chain or chain[-1][0] != 1:
+                    raise ValueError(f"Frame {frame_idx:04d} is delta-compressed but no base frame found")
+                base = decompress_frame(chain.pop(), None, None)
+            for dk in reversed(chain):
+                base = decompress_frame(dk, base[0], base[1])
+            prev_positions, prev_colors = base
+        return decompress_frame(data, prev_positions, prev_colors)
+    if nf.exists():
+        with np.load(nf) as d:
+            return d["positions"].copy(), d["colors"].copy()
+    raise FileNotFoundError(f"Frame {frame_idx:04d} not found")
+
+
+def compress_recording(rec_dir: Path, upto: int = None, batch_size: int = COMPRESSION_BATCH_SIZE):
+    """Convert raw frames to .zstd like the reference's BackgroundCompressor batches (:329-470):
+    within the run every frame after the very first is a delta against its predecessor."""
+    rec_dir = Path(rec_dir)
+    total = get_completed_frames(rec_dir) if upto is None else upto
+    prev = None
+    done = 0
+    for idx in range(total):
+        zf, nf = _frame_paths(rec_dir, idx)
+        if zf.exists():
+            prev = load_frame(rec_dir, idx, *(prev or (None, None)))
+            continue
+        with np.load(nf) as d:
+            cur = (d["positions"].copy(), d["colors"].copy())
+        blob = compress_frame(cur[0], cur[1], *(prev or (None, None)))
+        zf.write_bytes(blob)
+        nf.unlink()
+        # the decoder sees the quantised frame: chain on what it will reconstruct
+        prev = decompress_frame(blob, *(prev or (None, None)))
+        done += 1
+    return done
+
+
+# ---- initial conditions + the recording loop ---------------------------------------------------
+def _generate_initial_conditions(config: dict):
+    from tools.presets import generate_distribution
+    p, v, m = generate_distribution(config.get("distribution", "galaxy"), config["num_bodies"],
+                                    config["spawn_radius"], config["G"])
+    return p.astype(np.float64), v.astype(np.float64), m.astype(np.float64)
+
+
+def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = False, seed=None):
+    """The reference's record() on the GPU branch (:760-775, :821-876): per frame `substeps` x
+    step(dt_per_frame/substeps), compute_colors(15.0), get_positions, get_colors, raw frame;
+    velocities only every 50th frame for the state checkpoint.  Returns the session directory."""
+    from nbody.gpu_backend import Backend, create_gpu_simulation, get_backend
+
+    def say(*a):
+        if not quiet:
+            print(*a)
+
+    rec_dir = get_recording_dir(config["session_name"], root)
+    start_frame = 0
+    positions = velocities = masses = None
+    if resume:
+        completed = get_completed_frames(rec_dir)
+        if completed > 0:
+            state_file, state_frame = find_latest_state(rec_dir, completed)
+            if state_file is not None:
+                with np.load(state_file) as st:
+                    positions = st["positions"].astype(np.float64)
+                    velocities = st["velocities"].astype(np.float64)
+                    masses = st["masses"].astype(np.float64) if "masses" in st.files else None
+                start_frame = state_frame + 1
+                say(f"[Record] Resuming from frame {start_frame}")
+    if positions is None:
+        if seed is not None:
+            np.random.seed(seed)
+        positions, velocities, masses = _generate_initial_conditions(config)
+        save_metadata(rec_dir, config, time.time())
+    n = config["num_bodies"]
+    total_frames = config["total_frames"]
+    substeps = config["substeps"]
+    dt = config["dt_per_frame"] / substeps
+    if masses is None:
+        masses = np.ones(n, dtype=np.float64)  # reference :752-753 [quirk]
+
+    backend, info = get_backend()
+    if backend != Backend.HIP:
+        raise RuntimeError(f"[Record] no HIP backend ({info}); this build has no CPU fallback")
+    gpu_sim = create_gpu_simulation(positions, velocities, masses, config["G"], config["softening"],
+                                    config["damping"], theta=config.get("theta", 0.5), force_gpu=True)
+    if gpu_sim is None:
+        raise RuntimeError("[Record] create_gpu_simulation returned None")
+    say(f"[Record] GPU acceleration: {backend.value} - {info}")
+    t0 = time.time()
+    for frame in range(start_frame, total_frames):
+        gpu_sim.step_many(dt, substeps)
+        gpu_sim.compute_colors(15.0)
+        positions = gpu_sim.get_positions()
+        colors = gpu_sim.get_colors()
+        save_frame(rec_dir, frame, positions, colors)
+        if (frame + 1) % STATE_EVERY == 0:
+            np.savez(rec_dir / f"state_{frame:04d}.npz", positions=gpu_sim.get_positions_f64(),
+                     velocities=gpu_sim.get_velocities(), masses=masses)
+            old = rec_dir / f"state_{frame - STATE_EVERY:04d}.npz"
+            if old.exists():
+                old.unlink()
+    say(f"[Record] {total_frames - start_frame} frames in {time.time() - t0:.2f}s -> {rec_dir}")
+    gpu_sim.close()
+    return rec_dir

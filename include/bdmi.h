@@ -1,0 +1,61 @@
+/*
+ * bdmi.h - C ABI of the MI355X-native boids neighbour sweep (part of libnbmi.so).
+ *
+ * The reference has no backend seam for boids; its operator boundary is the five flat-array
+ * @njit kernels driven by Flock.update (reference boids/flock.py:627-678):
+ *   assign_cells              boids/flock.py:30-44   (get_cell_index :16-27)
+ *   np.argsort + build_cell_lists   boids/flock.py:610-625, :47-65
+ *   compute_flocking_spatial  boids/flock.py:68-238
+ *   update_physics_numba      boids/flock.py:241-308
+ * bdmi_step() is one Flock.update(dt): all four stages on the device, float64 state and
+ * arithmetic as in the reference, state resident in HBM between steps.
+ * Arrays crossing the boundary are C-order (N,3) float64, rows in the caller's boid order.
+ * Return codes / error string as in nbmi.h (bdmi_last_error == nbmi_last_error).
+ */
+#ifndef BDMI_H
+#define BDMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bdmi_flock bdmi_flock;
+
+/* params[11] in the order of reference config/boids.py:30-46:
+ * bounds, wall_margin, wall_weight, max_speed, max_force, perception_radius,
+ * separation_radius, separation_weight, alignment_weight, cohesion_weight, color_blend_rate.
+ * Grid as Flock.__init__ (flock.py:478-481): cell = perception_radius,
+ * dim = ceil(2*bounds/cell) + 2, offset = bounds + cell. */
+bdmi_flock *bdmi_create(int64_t n, const double *positions_xyz, const double *velocities_xyz,
+                        const double *colors_rgb, const double *params11, int device);
+void bdmi_destroy(bdmi_flock *f);
+const char *bdmi_last_error(void);
+
+/* `substeps` x Flock.update(dt) (flock.py:627-678), enqueued without host synchronisation. */
+int bdmi_step(bdmi_flock *f, double dt, int substeps);
+int bdmi_sync(bdmi_flock *f);
+
+/* positions / velocities / colors (N,3) float64 each; any pointer may be NULL. */
+int bdmi_get_state(bdmi_flock *f, double *positions_xyz, double *velocities_xyz, double *colors_rgb);
+int bdmi_set_state(bdmi_flock *f, const double *positions_xyz, const double *velocities_xyz,
+                   const double *colors_rgb);
+
+/* ---- parity hooks ------------------------------------------------------------------- */
+/* assign_cells output for the current positions: (N,) int32, caller's boid order. */
+int bdmi_get_cell_indices(bdmi_flock *f, int32_t *cell_indices);
+/* compute_flocking_spatial outputs for the current state (no physics applied):
+ * separation / alignment / cohesion forces and avg_colors, (N,3) float64 each, with the
+ * caller-side pre-fill of Flock.update (forces 0, avg_colors = colors; flock.py:633-636). */
+int bdmi_get_forces(bdmi_flock *f, double *sep, double *ali, double *coh, double *avg_colors);
+/* grid facts: dim, num_cells, non-empty cells of the last built grid. */
+int bdmi_grid_info(bdmi_flock *f, int32_t *grid_dim, int64_t *num_cells, int64_t *occupied);
+/* device ms accumulated per phase [cells+sort, reorder+table, sweep+physics], steps counted */
+int bdmi_enable_timers(bdmi_flock *f, int enable);
+int bdmi_get_timers(bdmi_flock *f, double *ms3, int64_t *count, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDMI_H */

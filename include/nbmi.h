@@ -1,0 +1,117 @@
+/*
+ * nbmi.h - C ABI of the MI355X-native N-body backend (libnbmi.so).
+ *
+ * This is the drop-in boundary for the reference's N-body *backend protocol*: the duck-typed
+ * object returned by create_gpu_simulation() (reference nbody/gpu_backend.py:623-679) whose
+ * methods are step / compute_colors / get_positions / get_velocities / get_colors / sync
+ * (reference class CUDASimulation, nbody/gpu_backend.py:336-409; Metal twin
+ * nbody/metal/metal_backend.py:246, 487-599).  One entry point per protocol method, plain
+ * pointers and sizes only.  All functions return 0 on success and a negative code on failure;
+ * nbmi_last_error() gives the message (thread-local).  A handle is used from one host thread
+ * at a time and owns one HIP stream.
+ *
+ * Body arrays crossing the boundary are the reference's layouts: positions / velocities are
+ * C-order (N,3), masses (N,), float64 in (as the reference constructors take them,
+ * gpu_backend.py:339-356), float32 positions / colours and float64 velocities out
+ * (gpu_backend.py:394-404).  Rows are always in the caller's original body order.
+ */
+#ifndef NBMI_H
+#define NBMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nbmi_sim nbmi_sim;
+
+#define NBMI_METHOD_BARNES_HUT 0 /* octree build + tree walk: nbody/simulation.py:63-305        */
+#define NBMI_METHOD_DIRECT 1     /* all-pairs O(N^2): nbody/gpu_backend.py:145-257               */
+
+#define NBMI_OK 0
+#define NBMI_ERR_ARG (-1)
+#define NBMI_ERR_HIP (-2)
+#define NBMI_ERR_NODEV (-3)
+#define NBMI_ERR_CAPACITY (-4) /* octree needs more than the 4N node rows the reference allocates */
+
+/* Number of visible HIP devices (0 if none / no driver).  Replaces the probe in
+ * detect_backend()/_check_cuda(), nbody/gpu_backend.py:36-70. */
+int nbmi_device_count(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char *nbmi_last_error(void);
+
+/* Constructor: CUDASimulation.__init__ (gpu_backend.py:339-366) /
+ * MetalBarnesHutSimulation.__init__(…, theta) (metal_backend.py:252-254).  Copies the three
+ * host arrays to the device; the caller keeps ownership.  Returns NULL on failure. */
+nbmi_sim *nbmi_create(int64_t n, const double *positions_xyz, const double *velocities_xyz,
+                      const double *masses, double G, double softening, double damping,
+                      double theta, int method, int device);
+
+void nbmi_destroy(nbmi_sim *sim);
+
+/* step(dt): gpu_backend.py:368-386.  `substeps` consecutive steps of size dt are enqueued on
+ * the handle's stream without host synchronisation (record() calls step() `substeps` times per
+ * frame, tools/record.py:823-824).  Barnes-Hut: bounds -> keys -> sort -> octree -> walk with the
+ * reference's kick-drift update fused in (simulation.py:308-317, 63-198, 201-278, 281-305). */
+int nbmi_step(nbmi_sim *sim, double dt, int substeps);
+
+/* compute_colors(max_speed): gpu_backend.py:388-392 (ramp of simulation.py:320-400). */
+int nbmi_compute_colors(nbmi_sim *sim, double max_speed);
+
+/* get_positions() -> (N,3) float32 (gpu_backend.py:394-396). */
+int nbmi_get_positions_f32(nbmi_sim *sim, float *out_xyz);
+/* get_velocities() -> (N,3) float64 (gpu_backend.py:398-400). */
+int nbmi_get_velocities_f64(nbmi_sim *sim, double *out_xyz);
+/* get_colors() -> (N,3) float32 (gpu_backend.py:402-404). */
+int nbmi_get_colors_f32(nbmi_sim *sim, float *out_rgb);
+/* sync(): gpu_backend.py:406-409.  Also reports deferred device-side errors (capacity). */
+int nbmi_sync(nbmi_sim *sim);
+
+/* ---- supersets of the protocol (parity / measurement hooks) --------------------------- */
+
+/* Full-precision state (float64 master copy kept on the device). */
+int nbmi_get_positions_f64(nbmi_sim *sim, double *out_xyz);
+/* Replace positions+velocities (resume from a state_%04d.npz, tools/record.py:728-733). */
+int nbmi_set_state(nbmi_sim *sim, const double *positions_xyz, const double *velocities_xyz);
+
+/* Build the octree for the CURRENT positions without advancing time (bounds, keys, sort,
+ * node emission).  After it the tree queries below describe that tree. */
+int nbmi_build_tree(nbmi_sim *sim);
+/* Accelerations (N,3) float64 of the current positions (build + walk, no integration):
+ * compute_forces_barnes_hut / compute_forces_*_cuda output. */
+int nbmi_get_accelerations_f64(nbmi_sim *sim, double *out_xyz);
+/* num_nodes as build_octree returns it (simulation.py:198), deepest level, root half-size
+ * (compute_bounds, simulation.py:317) of the most recently built tree. */
+int nbmi_tree_stats(nbmi_sim *sim, int64_t *num_nodes, int32_t *max_depth, double *bounds);
+/* Octant-path keys of every body for the most recently built tree, original body order:
+ * key_hi = levels 1..21 (3 bits per level, level 1 most significant, digit =
+ * x>=cx | (y>=cy)<<1 | (z>=cz)<<2 as get_octant, simulation.py:38-49), key_lo = levels 22..42. */
+int nbmi_get_keys(nbmi_sim *sim, uint64_t *key_hi, uint64_t *key_lo);
+/* (level, path key) of every node of the most recently built tree (num_nodes entries,
+ * unspecified order).  Keys of levels > 21 are reported as UINT64_MAX. */
+int nbmi_get_cells(nbmi_sim *sim, int32_t *level, uint64_t *key, int64_t capacity);
+/* Per-phase device time in ms accumulated since the last reset:
+ * [bounds+keys, sort, tree build, walk+integrate, other]; count = steps accumulated.
+ * Enabling timers adds hipEvent records to every step. */
+int nbmi_enable_timers(nbmi_sim *sim, int enable);
+int nbmi_get_timers(nbmi_sim *sim, double *ms5, int64_t *count, int reset);
+/* Work counters of the last walk: [wave-level node visits, lane-level visits, lane accepts]. */
+int nbmi_walk_counters(nbmi_sim *sim, int64_t *out3);
+
+/* Multi-GPU (one process per GPU).  A handle created with nbmi_create holds ALL bodies; with a
+ * shard set, step() integrates only the key-sorted ranks [begin,end) and leaves the others
+ * untouched until nbmi_import_shard() supplies them.  Packed row = 8 doubles
+ * {x,y,z,vx,vy,vz,m,id}.  Pointers are DEVICE pointers (e.g. torch tensors' data_ptr()) so the
+ * exchange itself can be an RCCL all-gather issued by the host framework. */
+int nbmi_set_shard(nbmi_sim *sim, int64_t begin, int64_t end);
+int nbmi_export_shard(nbmi_sim *sim, void *dev_rows);                              /* (end-begin, 8) f64 */
+int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_t end);
+/* Native HIP stream of the handle (for ordering against framework streams). */
+void *nbmi_stream(nbmi_sim *sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBMI_H */

@@ -1,0 +1,53 @@
+"""Test setup: markers, import paths, golden-fixture loader.
+
+`-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI load/exports (no GPU needed).
+`-m gpu`      : parity tests proper - HIP path through the C ABI vs the oracle / goldens.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_NAME = "3d-spatial-sim-for-boid-and-nbody_amd"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+# importing the (non-identifier-named) package puts its directory on sys.path so that the
+# reference's own module names (nbody, boids, tools, config) resolve to this build
+PKG = importlib.import_module(PKG_NAME)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyref
+    pyref.lib()  # builds with gcc if the .so is missing
+    return pyref
+
+
+def have_gpu():
+    try:
+        import nbmi_native
+        return nbmi_native.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """GPU tests must never silently pass without the HIP library and a device."""
+    import nbmi_native
+    nbmi_native.load()
+    assert nbmi_native.device_count() > 0, "gpu-marked test started without a HIP device"
+    return nbmi_native

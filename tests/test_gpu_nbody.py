@@ -1,0 +1,325 @@
+"""GPU parity tests for the N-body hot path: HIP kernels (through the C ABI / backend protocol)
+against the CPU oracle and the golden vectors of the reference.
+
+Stated tolerances
+  * bounds, octant-path keys, node counts, depth, the (level,key) cell set: bit-exact.
+  * accelerations (fp32 pair arithmetic vs float64 reference): per-body relative error
+    |a - a_ref| / |a_ref| <= 2e-4 max, <= 5e-6 median.
+  * positions after 100 steps: |x - x_ref| <= 1e-4 * max(|x_ref|, 0.05 * R) per body
+    (BASELINE north_star: <= 1e-4 relative position error after 100 steps).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TREES = ["tree_galaxy_256", "tree_galaxy_2048", "tree_collision_2048", "tree_cluster_2048"]
+
+
+def _bh(gpu, pos, vel, mass, G, eps, theta=0.5, damping=1.0):
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    return HIPBarnesHutSimulation(pos, vel, mass, G, eps, damping, theta)
+
+
+def _rel_err(a, ref):
+    return np.linalg.norm(a - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+
+
+def _sorted_cells(level, key):
+    idx = np.lexsort((key, level))
+    return np.stack([level[idx].astype(np.uint64), key[idx]], axis=1)
+
+
+@pytest.mark.parametrize("name", TREES)
+def test_tree_bit_exact(gpu, oracle, name):
+    g = golden(name)
+    pos, mass = g["pos"], g["mass"]
+    sim = _bh(gpu, pos, g["vel"], mass, float(g["G"]), float(g["eps"]))
+    sim.build_tree()
+    st = sim.tree_stats()
+    assert st["bounds"] == float(g["bounds"])            # compute_bounds, bit-exact
+    assert st["num_nodes"] == int(g["num_nodes"])        # build_octree return value
+    assert st["max_depth"] == int(g["max_depth"])
+    hi, lo = sim.morton_keys()
+    ohi, olo = oracle.body_keys(pos, st["bounds"])
+    assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    ll = g["leaf_level"].astype(np.uint64)
+    assert np.array_equal(hi >> (np.uint64(63) - np.uint64(3) * ll), g["leaf_key"])
+    level, key = sim.cells()
+    assert np.array_equal(_sorted_cells(level, key), g["cells"])
+    sim.close()
+
+
+@pytest.mark.parametrize("name", TREES)
+@pytest.mark.parametrize("theta,key", [(0.5, "acc_t050"), (0.95, "acc_t095")])
+def test_accelerations(gpu, oracle, name, theta, key):
+    g = golden(name)
+    pos, mass = g["pos"], g["mass"]
+    sim = _bh(gpu, pos, g["vel"], mass, float(g["G"]), float(g["eps"]), theta=theta)
+    acc = sim.accelerations()
+    err = _rel_err(acc, g[key])
+    print(f"{name} theta={theta}: rel err max {err.max():.3e} median {np.median(err):.3e}")
+    assert err.max() <= 2e-4 and np.median(err) <= 5e-6
+    # the set of accepted (body,node) pairs equals the reference's, up to fp32 ties in the test
+    b = oracle.compute_bounds(pos)
+    nd = oracle.NodeArrays.for_bodies(len(pos))
+    nn = oracle.build_octree(pos, mass, b, nd)
+    _, st = oracle.compute_forces_barnes_hut(pos, mass, nd, nn, theta, float(g["G"]), float(g["eps"]), stats=True)
+    wc = sim.walk_counters()
+    print("   counters", wc, "oracle", st)
+    assert abs(wc["lane_accepts"] - st["accepted"]) <= max(2, 1e-4 * st["accepted"])
+    sim.close()
+
+
+def test_edge_cases(gpu, oracle):
+    g = golden("tree_edge_cases")
+    for tag in ["n1", "n2", "lattice", "close_pairs", "heavy"]:
+        pos, mass = g[tag + "_pos"], g[tag + "_mass"]
+        sim = _bh(gpu, pos, np.zeros_like(pos), mass, 1.0, 0.1)
+        sim.build_tree()
+        st = sim.tree_stats()
+        assert st["bounds"] == float(g[tag + "_bounds"]), tag
+        assert st["num_nodes"] == int(g[tag + "_num_nodes"]), tag
+        assert st["max_depth"] == int(g[tag + "_max_depth"]), tag
+        level, key = sim.cells()
+        assert np.array_equal(_sorted_cells(level, key), g[tag + "_cells"]), tag
+        acc = sim.accelerations()
+        ref = g[tag + "_acc"]
+        scale = np.abs(ref).max() + 1e-30
+        assert np.abs(acc - ref).max() <= 2e-4 * scale, tag
+        sim.close()
+
+
+def test_empty_and_single(gpu):
+    from nbody.gpu_backend import HIPBarnesHutSimulation, HIPDirectSimulation
+    z = np.zeros((0, 3))
+    for cls, extra in ((HIPBarnesHutSimulation, (0.5,)), (HIPDirectSimulation, ())):
+        s = cls(z, z, np.zeros(0), 1.0, 0.1, 1.0, *extra)
+        s.step(0.1)
+        s.compute_colors(15.0)
+        assert s.get_positions().shape == (0, 3) and s.get_velocities().shape == (0, 3)
+        s.sync()
+        s.close()
+    s = HIPBarnesHutSimulation(np.array([[1.0, 2.0, 3.0]]), np.array([[0.5, 0.0, -1.0]]), np.array([2.0]), 1.0, 0.1,
+                               1.0, 0.5)
+    s.step(0.25)
+    assert np.allclose(s.get_positions_f64(), [[1.125, 2.0, 2.75]], rtol=0, atol=1e-15)
+    assert s.tree_stats()["num_nodes"] == 1
+    s.close()
+
+
+def test_capacity_error_is_reported_not_hung(gpu):
+    """Reference allocates 4N node rows and would write out of bounds; here it is an error."""
+    rng = np.random.RandomState(5)
+    base = rng.uniform(-50, 50, (1500, 3))
+    pos = np.concatenate([base, base + 1e-9])
+    sim = _bh(gpu, pos, np.zeros_like(pos), np.ones(len(pos)), 1.0, 0.1)
+    with pytest.raises(RuntimeError, match="octree needs"):
+        sim.build_tree()
+    with pytest.raises(RuntimeError):
+        sim.step(0.1)
+        sim.sync()
+    sim.close()
+
+
+def test_coincident_bodies_terminate(gpu):
+    """Exactly coincident bodies make the reference subdivide until its node cap; here the key
+    runs out at 42 levels and both become leaves of the level-42 cell.  Must terminate."""
+    pos = np.array([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [-3.0, 2.0, 0.5], [4.0, -1.0, 2.0]])
+    pos = np.concatenate([pos, np.random.RandomState(0).uniform(-5, 5, (60, 3))])
+    sim = _bh(gpu, pos, np.zeros_like(pos), np.ones(len(pos)), 1.0, 0.1)
+    sim.build_tree()
+    st = sim.tree_stats()
+    assert st["max_depth"] == 43
+    acc = sim.accelerations()
+    assert np.isfinite(acc).all()
+    assert np.allclose(acc[0], acc[1])
+    sim.close()
+
+
+def _traj_check(x, ref, R, what):
+    d = np.linalg.norm(x - ref, axis=1)
+    scale = np.maximum(np.linalg.norm(ref, axis=1), 0.05 * R)
+    rel = d / scale
+    print(f"{what}: rel pos err max {rel.max():.3e} p99 {np.percentile(rel, 99):.3e} median {np.median(rel):.3e}")
+    return rel
+
+
+def test_trajectory_2048_100_steps(gpu):
+    g = golden("traj_galaxy_2048")
+    sim = _bh(gpu, g["pos_0"], g["vel_0"], g["mass"], float(g["G"]), float(g["eps"]), theta=float(g["theta"]),
+              damping=float(g["damping"]))
+    dt = float(g["dt"])
+    nn = g["num_nodes_per_step"]
+    done = 0
+    for s in (1, 10, 100):
+        if s == 1:
+            sim.step(dt)
+            assert sim.tree_stats()["num_nodes"] == int(nn[0])  # same positions -> same tree
+        else:
+            sim.step_many(dt, s - done)
+        done = s
+        rel = _traj_check(sim.get_positions_f64(), g[f"pos_{s}"], 500.0, f"galaxy2048 step {s}")
+        assert rel.max() <= 1e-4
+        v = sim.get_velocities()
+        assert np.abs(v - g[f"vel_{s}"]).max() <= 1e-4 * np.abs(g[f"vel_{s}"]).max()
+    assert abs(sim.tree_stats()["num_nodes"] - int(nn[99])) <= 0.002 * int(nn[99])
+    sim.compute_colors(15.0)
+    col = sim.get_colors()
+    assert col.dtype == np.float32 and np.abs(col - g["col_100"]).max() <= 2e-3
+    sim.close()
+
+
+def test_config1_quick_galaxy_10k_100_steps(gpu):
+    """BASELINE config 1 end to end: IC generator -> 100 GPU steps vs the reference's own run."""
+    from tools.presets import generate_distribution
+    g = golden("traj_galaxy_10k")
+    np.random.seed(42)
+    p, v, m = generate_distribution("galaxy", 10_000, 500.0, 0.15)
+    sim = _bh(gpu, p, v, m, 0.15, 3.0, theta=0.5)
+    sim.step(0.2)
+    assert sim.tree_stats()["num_nodes"] == int(g["num_nodes_per_step"][0])
+    sim.step_many(0.2, 99)
+    rel = _traj_check(sim.get_positions_f64(), g["pos_100"], 500.0, "galaxy10k step 100")
+    assert rel.max() <= 1e-4
+    assert np.abs(sim.get_velocities() - g["vel_100"]).max() <= 1e-4 * np.abs(g["vel_100"]).max()
+    sim.close()
+
+
+def test_rows_stay_in_caller_order(gpu):
+    """State is re-sorted on the device every step; getters must undo that."""
+    g = golden("tree_collision_2048")
+    sim = _bh(gpu, g["pos"], g["vel"], g["mass"], float(g["G"]), float(g["eps"]))
+    p0 = sim.get_positions_f64()
+    assert np.array_equal(p0, g["pos"]) and np.array_equal(sim.get_velocities(), g["vel"])
+    sim.step_many(0.01, 5)
+    p5 = sim.get_positions_f64()
+    v5 = sim.get_velocities()
+    assert np.abs(p5 - (g["pos"] + 0.05 * g["vel"])).max() < 0.05  # nobody teleported
+    f32 = sim.get_positions()
+    assert f32.dtype == np.float32 and np.array_equal(f32, p5.astype(np.float32))
+    sim.set_state(g["pos"], g["vel"])
+    assert np.array_equal(sim.get_positions_f64(), g["pos"]) and np.array_equal(sim.get_velocities(), g["vel"])
+    sim.step_many(0.01, 5)
+    assert np.array_equal(sim.get_positions_f64(), p5) and np.array_equal(sim.get_velocities(), v5)  # deterministic
+    sim.close()
+
+
+def test_colors_ramp_bit_exact(gpu):
+    g = golden("colors_ramp")
+    vel = g["vel"]
+    sim = _bh(gpu, np.random.RandomState(0).normal(0, 10, vel.shape), vel, np.ones(len(vel)), 1.0, 0.1)
+    sim.compute_colors(float(g["max_speed"]))
+    assert np.array_equal(sim.get_colors(), g["colors"])
+    sim.close()
+
+
+@pytest.mark.parametrize("name", ["direct_cluster_2048", "direct_galaxy_2048"])
+def test_direct_n2(gpu, name):
+    from nbody.gpu_backend import HIPDirectSimulation
+    g = golden(name)
+    sim = HIPDirectSimulation(g["pos"], g["vel"], g["mass"], float(g["G"]), float(g["eps"]), float(g["damping"]))
+    err = _rel_err(sim.accelerations(), g["acc"])
+    print(f"{name}: rel err max {err.max():.3e} median {np.median(err):.3e}")
+    assert err.max() <= 5e-5 and np.median(err) <= 2e-6
+    sim.step(float(g["dt"]))
+    assert np.allclose(sim.get_positions_f64(), g["pos_1"], rtol=0, atol=1e-7)
+    assert np.allclose(sim.get_velocities(), g["vel_1"], rtol=0, atol=1e-6 * np.abs(g["vel_1"]).max())
+    sim.close()
+
+
+def test_direct_matches_oracle_mid_size(gpu, oracle):
+    """All three register-blocking variants (1, 2, 4 bodies per thread), ragged sizes."""
+    from nbody.gpu_backend import HIPDirectSimulation
+    rng = np.random.RandomState(11)
+    for n in (1000, 131_073, 524_289):
+        pos = rng.normal(0, 100, (n, 3))
+        m = rng.uniform(0.5, 2.0, n)
+        sim = HIPDirectSimulation(pos, np.zeros_like(pos), m, 0.05, 1.0, 1.0)
+        acc = sim.accelerations()
+        sample = rng.choice(n, 256, replace=False)
+        d = pos[None, :, :] - pos[sample][:, None, :]
+        r2 = (d * d).sum(-1) + 1.0
+        w = 0.05 * m[None, :] * r2 ** -1.5
+        ref = (w[:, :, None] * d).sum(1)
+        err = _rel_err(acc[sample], ref)
+        print(f"direct n={n}: rel err max {err.max():.3e}")
+        assert err.max() <= 5e-5
+        sim.close()
+
+
+def test_backend_protocol_and_factory(gpu):
+    from nbody import gpu_backend as gb
+    saved = (gb._BACKEND, gb._BACKEND_INFO)
+    try:
+        gb._BACKEND = None
+        backend, _ = gb.get_backend()
+        assert backend == gb.Backend.HIP
+        g = golden("tree_galaxy_256")
+        sim = gb.create_gpu_simulation(g["pos"], g["vel"], g["mass"], 0.15, 3.0, 1.0, theta=0.5)
+        assert isinstance(sim, gb.HIPBarnesHutSimulation)
+        for name in ("step", "compute_colors", "get_positions", "get_velocities", "get_colors", "sync"):
+            assert callable(getattr(sim, name))
+        sim.step(0.1)
+        sim.compute_colors(15.0)
+        assert sim.get_positions().dtype == np.float32 and sim.get_velocities().dtype == np.float64
+        assert sim.get_colors().shape == (256, 3)
+        sim.sync()
+        d = gb.create_gpu_simulation(g["pos"], g["vel"], g["mass"], 0.15, 3.0, 1.0, method="direct")
+        assert isinstance(d, gb.HIPDirectSimulation)
+        with pytest.raises(ValueError):
+            gb.HIPBarnesHutSimulation(g["pos"], g["vel"][:10], g["mass"], 0.15, 3.0, 1.0)
+    finally:
+        gb._BACKEND, gb._BACKEND_INFO = saved
+
+
+def test_nbody_simulation_object(gpu):
+    from nbody import NBodySimulation
+    sim = NBodySimulation(20_000, seed=3)
+    assert sim.positions.shape == (20_000, 3) and sim.colors.dtype == np.float32 and sim._use_gpu
+    p0 = sim.positions.copy()
+    sim.update(0.05)  # capped to 0.02 inside
+    assert sim.positions.dtype == np.float64 and sim._num_tree_nodes > 20_000
+    assert np.abs(sim.positions - (p0 + 0.02 * sim.velocities)).max() < 0.05
+    assert sim.colors.min() >= 0.0 and sim.colors.max() <= 1.0 and sim.colors.any()
+    with pytest.raises(NotImplementedError):
+        sim.draw()
+
+
+def test_galaxy_1m_tree_and_forces_vs_oracle(gpu, oracle):
+    """BASELINE config 2 inputs (galaxy 1 M, R=800, G=0.07, eps=1.5, theta=0.5): node count and
+    depth equal the oracle's serial-insertion tree; accelerations within the fp32 tolerance."""
+    from tools.presets import generate_distribution
+    np.random.seed(42)
+    p, v, m = generate_distribution("galaxy", 1_000_000, 800.0, 0.07)
+    sim = _bh(gpu, p, v, m, 0.07, 1.5, theta=0.5)
+    sim.build_tree()
+    st = sim.tree_stats()
+    b = oracle.compute_bounds(p)
+    nd = oracle.NodeArrays.for_bodies(len(p))
+    nn = oracle.build_octree(p, m, b, nd)
+    level, _ = oracle.tree_cells(nd, nn)
+    print("1M tree:", st, "oracle nodes", nn, "depth", int(level.max()))
+    assert st["bounds"] == b and st["num_nodes"] == nn and st["max_depth"] == int(level.max())
+    hi, lo = sim.morton_keys()
+    ohi, olo = oracle.body_keys(p, b)
+    assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    acc = sim.accelerations()
+    ref, ost = oracle.compute_forces_barnes_hut(p, m, nd, nn, 0.5, 0.07, 1.5, stats=True)
+    err = _rel_err(acc, ref)
+    wc = sim.walk_counters()
+    print(f"1M acc rel err max {err.max():.3e} p99.9 {np.percentile(err, 99.9):.3e} median {np.median(err):.3e}")
+    print("   counters", wc, "oracle", ost)
+    assert ost["dropped"] == 0
+    assert np.median(err) <= 5e-6 and np.percentile(err, 99.9) <= 2e-4 and err.max() <= 5e-3
+    assert abs(wc["lane_accepts"] - ost["accepted"]) <= 1e-4 * ost["accepted"]
+    # 3 steps vs the oracle stepper
+    ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0)
+    for _ in range(3):
+        ostep.step(0.05)
+    sim.step_many(0.05, 3)
+    rel = _traj_check(sim.get_positions_f64(), ostep.pos, 800.0, "galaxy1m step 3")
+    assert rel.max() <= 1e-5
+    sim.close()
