@@ -15,6 +15,7 @@ void clear_error();
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
         if (_e != hipSuccess) {                                                             \
+            (void)hipGetLastError(); /* clear the sticky error so later calls start clean */ \
             nbmi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                             __LINE__);                                                      \
             return -2;                                                                      \

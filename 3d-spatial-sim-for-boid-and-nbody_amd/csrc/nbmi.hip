@@ -76,6 +76,8 @@ struct TreeInfo {
     int max_level;                   // deepest leaf level
     int error;                       // 1 = node capacity exceeded
     unsigned long long wave_visits, lane_visits, lane_accepts;
+    unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
+    unsigned long long jumps;        // cursor moves other than c -> c+1
 };
 
 // ---------------------------------------------------------------------------------------
@@ -330,6 +332,8 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     int resume = valid ? 0 : 0x7fffffff;
     float ax = 0.f, ay = 0.f, az = 0.f;
     unsigned long long wv = 0, lv = 0, la = 0;
+    unsigned long long wm[4] = {0, 0, 0, 0}, jm = 0;
+    int wbase[4] = {-1000, -1000, -1000, -1000};
 
     int c = 0;
     while (c < nn) {
@@ -351,18 +355,27 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         az = fmaf(dz, f, az);
         if (take) resume = nd.next;
         const unsigned long long any_open = __ballot(open);
+        const int nxt_c = nd.next > c ? nd.next : c + 1;
         if (kCount) {
             wv += 1;
             lv += active ? 1 : 0;
             la += force ? 1 : 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (c < wbase[w] || c >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c; }
+            }
+            jm += (!any_open && nxt_c != c + 1) ? 1 : 0;
         }
-        const int nxt_c = nd.next > c ? nd.next : c + 1;
         c = any_open ? c + 1 : nxt_c;
     }
 
     if (kCount) {
         // wave_visits counted once per wave (lane 0), lane counters summed over lanes
-        if ((threadIdx.x & 63) == 0) atomicAdd(&info_out->wave_visits, wv);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&info_out->wave_visits, wv);
+            for (int w = 0; w < 4; w++) atomicAdd(&info_out->win_miss[w], wm[w]);
+            atomicAdd(&info_out->jumps, jm);
+        }
         atomicAdd(&info_out->lane_visits, lv);
         atomicAdd(&info_out->lane_accepts, la);
     }
@@ -775,7 +788,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
     NBMI_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto &e : s->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
     if (alloc_bodies(s, &s->buf[0], n) || alloc_bodies(s, &s->buf[1], n)) return -2;
-    if (dev_alloc(s, &s->posm_s, n) || dev_alloc(s, &s->colors, 3 * n) || dev_alloc(s, &s->info, 1)) return -2;
+    if (dev_alloc(s, &s->posm_s, n) || dev_alloc(s, &s->colors, 3 * (n ? n : 1)) || dev_alloc(s, &s->info, 1)) return -2;
     void *stage = nullptr;
     NBMI_HIP_CHECK(hipMalloc(&stage, (size_t)(n ? n : 1) * 7 * sizeof(double)));
     s->allocs.push_back(stage);
@@ -981,7 +994,7 @@ int nbmi_get_accelerations_f64(nbmi_sim *s, double *out) {
     double *acc = (double *)s->stage;
     if (s->method == NBMI_METHOD_BARNES_HUT) {
         if (int rc = enqueue_tree(s, -1)) return rc;
-        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 3 * sizeof(unsigned long long), s->stream));
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 8 * sizeof(unsigned long long), s->stream));
         if (int rc = enqueue_walk(s, false, 0.0, acc)) return rc;
     } else {
         if (int rc = launch_direct<false>(s, 0.0, acc)) return rc;
@@ -1078,13 +1091,16 @@ int nbmi_get_timers(nbmi_sim *s, double *ms5, int64_t *count, int reset) {
     return 0;
 }
 
-int nbmi_walk_counters(nbmi_sim *s, int64_t *out3) {
+int nbmi_walk_counters(nbmi_sim *s, int64_t *out8) {
     if (int rc = check_handle(s)) return rc;
+    int64_t *out3 = out8;
     if (!out3) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     out3[0] = (int64_t)h.wave_visits; out3[1] = (int64_t)h.lane_visits; out3[2] = (int64_t)h.lane_accepts;
+    for (int w = 0; w < 4; w++) out8[3 + w] = (int64_t)h.win_miss[w];
+    out8[7] = (int64_t)h.jumps;
     return 0;
 }
 

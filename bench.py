@@ -195,7 +195,10 @@ def main():
                                "wave_visits_per_group": wc["wave_visits"] / max(1, (n_total + 63) // 64),
                                "lane_visits_per_body": wc["lane_visits"] / n_total,
                                "interactions_per_s": wc["lane_accepts"] / (walk_ms * 1e-3),
-                               "num_nodes": ts["num_nodes"], "max_depth": ts["max_depth"]}
+                               "num_nodes": ts["num_nodes"], "max_depth": ts["max_depth"],
+                               "window_misses_per_group": {str(k): v / max(1, (n_total + 63) // 64)
+                                                           for k, v in wc["window_misses"].items()},
+                               "jumps_per_group": wc["jumps"] / max(1, (n_total + 63) // 64)}
         else:
             flops = 20.0 * n_total * n_total
             ach = flops / (walk_ms * 1e-3) / 1e12

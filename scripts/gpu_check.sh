@@ -20,4 +20,13 @@ nproc | tee -a gpurun_out/summary.log
 run smoke 600 python -c "import __graft_entry__ as g; g.smoke()"
 run pytest_gpu ${PYTEST_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA -p no:cacheprovider ${PYTEST_ARGS:-}
 run bench 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2
+if [ -n "${PROFILE:-}" ]; then
+  cd /tmp
+  run_dir=$GRAFT_REPO_ROOT/gpurun_out/prof_$PROFILE
+  rm -rf "$run_dir"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$run_dir" -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+  echo "=== rocprof rc=$?" | tee -a $GRAFT_REPO_ROOT/gpurun_out/summary.log
+  cd $GRAFT_REPO_ROOT
+  find "$run_dir" -name "*stats*.csv" | head
+fi
 exit 0
