@@ -25,6 +25,7 @@
 //     wave-uniform cursor (scalar loads); every lane applies the reference's own per-body
 //     opening test; the wave descends if ANY lane opens, lanes that accepted an ancestor sit
 //     out until the cursor leaves that subtree.  Each lane's accepted set == the reference's.
+#include <math.h>
 #include <stdarg.h>
 #include <stddef.h>
 #include <string.h>
@@ -57,7 +58,7 @@ constexpr int kMaxLevel = 42;  // key digits available (2 x 21)
 struct alignas(32) Node {
     float cx, cy, cz;  // centre of mass (leaf: the body's position)
     float gm;          // G * mass
-    float size2;       // (2*half_size)^2, 0 for leaves
+    float s2t;         // (2*half_size)^2 / theta^2 (accept when s2t < dist_sq); 0 for leaves
     int next;          // index of the first node after this node's subtree
     int ref;           // leaf: sorted rank of its body (>= 0); internal: ~(rank of first body)
     int level;         // depth, root = 0
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ h
 __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
                                                  const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
                                                  const Moment *__restrict__ S, const float4 *__restrict__ posm_s,
-                                                 int64_t n, double G, int64_t capacity, Node *__restrict__ nodes,
-                                                 TreeInfo *info) {
+                                                 int64_t n, double G, double inv_theta2, int64_t capacity,
+                                                 Node *__restrict__ nodes, TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const double bounds = info->bounds;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
         Node nd;
         nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
         nd.gm = (float)(G * M);
-        nd.size2 = (float)(size * size);
+        nd.s2t = (float)(size * size * inv_theta2);
         nd.next = (int)(e + (int64_t)Pex[e]);
         nd.ref = ~(int)r;
         nd.level = lev;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
     const int leaf_level = (d > dp ? d : dp) + 1;
     Node lf;
     lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
-    lf.size2 = 0.0f;
+    lf.s2t = 0.0f;
     lf.next = (int)(base + cnt + 1);
     lf.ref = (int)r;
     lf.level = leaf_level;
@@ -297,10 +298,13 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
 
 // ---------------------------------------------------------------------------------------
 // K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor `c` over the
-// pre-order node array; per lane the reference's test (simulation.py:245-274):
-//     skip own leaf; d = com - p; dist_sq = |d|^2 + eps^2;
-//     accept if leaf or (2 hs)^2 < theta^2 dist_sq      [== 2hs/dist < theta]
+// pre-order node array (one scalar s_load_dwordx8 per visit); per lane the reference's test
+// (simulation.py:245-274):
+//     d = com - p; dist_sq = |d|^2 + eps^2;
+//     accept if leaf or 2 hs / dist < theta          [== (2hs)^2/theta^2 < dist_sq; leaves carry 0]
 //     accepted && mass>0 && dist_sq > eps^2  ->  a += G m d / dist^3
+// The reference's explicit "skip my own leaf" needs no instruction here: the own leaf has d = 0
+// exactly, so its term is 0 (eps > 0) or fails the dist_sq > eps^2 guard (kGuard, eps == 0).
 // `resume` = first node index at which the lane takes part again (it accepted an ancestor of
 // everything before that).  The cursor moves to c+1 if any lane opens the node, else to
 // node.next.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
@@ -309,11 +313,11 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
 struct WalkParams {
     int64_t n;
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
-    float theta2, eps2;
+    float eps2;
     double dt, damping;
 };
 
-template <bool kIntegrate, bool kCount>
+template <bool kIntegrate, bool kCount, bool kGuard>
 __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const TreeInfo *info_in,
                                                  const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
                                                  Bodies cur, Bodies nxt, double *__restrict__ acc_out, WalkParams P,
@@ -328,7 +332,6 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         const float4 p = posm_s[rank];
         px = p.x; py = p.y; pz = p.z;
     }
-    const int myrank = valid ? (int)rank : -2;
     int resume = valid ? 0 : 0x7fffffff;
     float ax = 0.f, ay = 0.f, az = 0.f;
     unsigned long long wv = 0, lv = 0, la = 0;
@@ -338,35 +341,40 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     int c = 0;
     while (c < nn) {
         c = __builtin_amdgcn_readfirstlane(c);
-        const Node nd = nodes[c];
+        // byte offset as an unsigned 32-bit scalar: s_load with an SGPR offset, no 64-bit address maths
+        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) +
+                                                        ((unsigned)c << 5));
         const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
-        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        const float dist_sq = d2 + P.eps2;
+        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
         const bool active = resume <= c;
-        const bool leaf = nd.ref >= 0;
-        const bool geom = leaf || (nd.size2 < P.theta2 * dist_sq);
+        // both operands are non-negative floats: compare their bit patterns as integers (the
+        // compiler folds an integer compare straight into the ballot's lane mask)
+        const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
+        const unsigned long long m_active = __builtin_amdgcn_ballot_w64(active);
+        const unsigned long long m_geom = __builtin_amdgcn_ballot_w64(geom);
         const bool take = active && geom;
-        const bool open = active && !geom;
-        const bool force = take && (nd.ref != myrank) && (d2 > 0.f);
+        bool force = take;
+        if (kGuard) force = take && (dist_sq > P.eps2);
         const float inv = __builtin_amdgcn_rsqf(dist_sq);
         const float f = force ? nd.gm * inv * inv * inv : 0.f;
         ax = fmaf(dx, f, ax);
         ay = fmaf(dy, f, ay);
         az = fmaf(dz, f, az);
-        if (take) resume = nd.next;
-        const unsigned long long any_open = __ballot(open);
-        const int nxt_c = nd.next > c ? nd.next : c + 1;
+        resume = take ? nd.next : resume;
+        const unsigned long long any_open = m_active & ~m_geom;
+        const int seq = c + 1;
+        const int nxt_c = nd.next > seq ? nd.next : seq;
         if (kCount) {
             wv += 1;
             lv += active ? 1 : 0;
-            la += force ? 1 : 0;
+            la += (take && dist_sq > P.eps2) ? 1 : 0;
 #pragma unroll
             for (int w = 0; w < 4; w++) {
                 if (c < wbase[w] || c >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c; }
             }
-            jm += (!any_open && nxt_c != c + 1) ? 1 : 0;
+            jm += (!any_open && nxt_c != seq) ? 1 : 0;
         }
-        c = any_open ? c + 1 : nxt_c;
+        c = any_open ? seq : nxt_c;
     }
 
     if (kCount) {
@@ -383,14 +391,16 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     const uint32_t j = perm[rank];
     if (kIntegrate) {
         double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+        const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
+        const int32_t id0 = cur.id[j];
         vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
         vx *= P.damping; vy *= P.damping; vz *= P.damping;
         nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
-        nxt.x[rank] = cur.x[j] + vx * P.dt;
-        nxt.y[rank] = cur.y[j] + vy * P.dt;
-        nxt.z[rank] = cur.z[j] + vz * P.dt;
-        nxt.m[rank] = cur.m[j];
-        nxt.id[rank] = cur.id[j];
+        nxt.x[rank] = x0 + vx * P.dt;
+        nxt.y[rank] = y0 + vy * P.dt;
+        nxt.z[rank] = z0 + vz * P.dt;
+        nxt.m[rank] = m0;
+        nxt.id[rank] = id0;
     } else {
         const int64_t o = 3 * (int64_t)cur.id[j];
         acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
@@ -681,7 +691,9 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     k_delta<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, n, s->delta, s->cnt);
     NBMI_HIP_CHECK(nbmi::exclusive_scan_i32(s->tmp_scan_i, s->tmp_scan_i_bytes, s->cnt, s->Pex, (size_t)n + 1, st));
     NBMI_HIP_CHECK(nbmi::exclusive_scan_moment(s->tmp_scan_m, s->tmp_scan_m_bytes, s->W, s->S, (size_t)n + 1, st));
-    k_emit<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->delta, s->Pex, s->S, s->posm_s, n, s->G,
+    // theta = 0 means "never accept an internal node": s2t = +inf
+    const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
+    k_emit<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->delta, s->Pex, s->S, s->posm_s, n, s->G, inv_theta2,
                                           s->node_capacity, s->nodes, s->info);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], st));
     NBMI_HIP_CHECK(hipGetLastError());
@@ -697,21 +709,21 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.n = n;
     P.rank_begin = integrate ? s->shard_begin : 0;
     P.rank_end = integrate ? s->shard_end : n;
-    P.theta2 = (float)(s->theta * s->theta);
     P.eps2 = (float)(s->softening * s->softening);
+    const bool guard = !(P.eps2 > 0.f);
     P.dt = dt;
     P.damping = s->damping;
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
     const int gb = nblocks(cntr);
+#define NBMI_WALK(I, C, G) \
+    k_walk<I, C, G><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
     if (integrate) {
-        if (s->count_walk)
-            k_walk<true, true><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, nullptr, P, s->info);
-        else
-            k_walk<true, false><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, nullptr, P, s->info);
+        if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
     } else {
-        k_walk<false, true><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info);
+        if (guard) NBMI_WALK(false, true, true); else NBMI_WALK(false, true, false);
     }
+#undef NBMI_WALK
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
