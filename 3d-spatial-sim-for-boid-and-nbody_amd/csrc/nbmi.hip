@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -314,72 +315,119 @@ struct WalkParams {
     int64_t n;
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
     float eps2;
+    int xcd_remap;
     double dt, damping;
 };
 
-template <bool kIntegrate, bool kCount, bool kGuard>
+// One node visit of cursor `c` for the lane's body (px,py,pz): returns the next cursor value.
+template <bool kGuard>
+__device__ __forceinline__ int visit(const Node *__restrict__ nodes, int c, float px, float py, float pz, float eps2,
+                                     int &resume, float &ax, float &ay, float &az, bool &active_out,
+                                     bool &force_out, bool &jumped) {
+    c = __builtin_amdgcn_readfirstlane(c);
+    // byte offset as an unsigned 32-bit scalar: s_load with an SGPR offset, no 64-bit address maths
+    const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + ((unsigned)c << 5));
+    const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
+    const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
+    const bool active = resume <= c;
+    // both operands are non-negative floats: compare their bit patterns as integers (the
+    // compiler folds an integer compare straight into the ballot's lane mask)
+    const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
+    const unsigned long long m_active = __builtin_amdgcn_ballot_w64(active);
+    const unsigned long long m_geom = __builtin_amdgcn_ballot_w64(geom);
+    const bool take = active && geom;
+    bool force = take;
+    if (kGuard) force = take && (dist_sq > eps2);
+    const float inv = __builtin_amdgcn_rsqf(dist_sq);
+    const float f = force ? nd.gm * inv * inv * inv : 0.f;
+    ax = fmaf(dx, f, ax);
+    ay = fmaf(dy, f, ay);
+    az = fmaf(dz, f, az);
+    resume = take ? nd.next : resume;
+    const unsigned long long any_open = m_active & ~m_geom;
+    const int seq = c + 1;
+    const int nxt_c = nd.next;  // k_emit guarantees next > c; a flagged (overflowed) build is never walked
+    active_out = active;
+    force_out = take && (dist_sq > eps2);
+    jumped = !any_open && nxt_c != seq;
+    return any_open ? seq : nxt_c;
+}
+
+// kCur independent cursors per wave: lane l carries the bodies of ranks base + k*64 + l
+// (k < kCur), i.e. kCur adjacent 64-body groups, each walked by its own wave-uniform cursor.
+// The chains are independent, so their scalar-load latencies overlap (the single-cursor walk is
+// bound by the load -> compare -> branch dependency of one wave, not by VALU issue).
+template <bool kIntegrate, bool kCount, bool kGuard, int kCur>
 __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const TreeInfo *info_in,
                                                  const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
                                                  Bodies cur, Bodies nxt, double *__restrict__ acc_out, WalkParams P,
                                                  TreeInfo *info_out) {
-    const int lb = logical_block(blockIdx.x, gridDim.x);
-    const int64_t rank = P.rank_begin + (int64_t)lb * kBlock + threadIdx.x;
-    const bool valid = rank < P.rank_end;
+    const int lb = P.xcd_remap ? logical_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t base = P.rank_begin + ((int64_t)lb * (blockDim.x >> 6) + wave) * (64 * kCur) + lane;
     const int nn = (info_in->error != 0) ? 0 : (int)info_in->num_nodes;
 
-    float px = 0.f, py = 0.f, pz = 0.f;
-    if (valid) {
-        const float4 p = posm_s[rank];
-        px = p.x; py = p.y; pz = p.z;
+    float px[kCur], py[kCur], pz[kCur], ax[kCur], ay[kCur], az[kCur];
+    int resume[kCur], c[kCur];
+    bool valid[kCur];
+#pragma unroll
+    for (int k = 0; k < kCur; k++) {
+        const int64_t rank = base + (int64_t)k * 64;
+        valid[k] = rank < P.rank_end;
+        px[k] = py[k] = pz[k] = 0.f;
+        if (valid[k]) {
+            const float4 p = posm_s[rank];
+            px[k] = p.x; py[k] = p.y; pz[k] = p.z;
+        }
+        resume[k] = valid[k] ? 0 : 0x7fffffff;
+        ax[k] = ay[k] = az[k] = 0.f;
+        c[k] = 0;
     }
-    int resume = valid ? 0 : 0x7fffffff;
-    float ax = 0.f, ay = 0.f, az = 0.f;
     unsigned long long wv = 0, lv = 0, la = 0;
     unsigned long long wm[4] = {0, 0, 0, 0}, jm = 0;
     int wbase[4] = {-1000, -1000, -1000, -1000};
 
-    int c = 0;
-    while (c < nn) {
-        c = __builtin_amdgcn_readfirstlane(c);
-        // byte offset as an unsigned 32-bit scalar: s_load with an SGPR offset, no 64-bit address maths
-        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) +
-                                                        ((unsigned)c << 5));
-        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
-        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
-        const bool active = resume <= c;
-        // both operands are non-negative floats: compare their bit patterns as integers (the
-        // compiler folds an integer compare straight into the ballot's lane mask)
-        const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
-        const unsigned long long m_active = __builtin_amdgcn_ballot_w64(active);
-        const unsigned long long m_geom = __builtin_amdgcn_ballot_w64(geom);
-        const bool take = active && geom;
-        bool force = take;
-        if (kGuard) force = take && (dist_sq > P.eps2);
-        const float inv = __builtin_amdgcn_rsqf(dist_sq);
-        const float f = force ? nd.gm * inv * inv * inv : 0.f;
-        ax = fmaf(dx, f, ax);
-        ay = fmaf(dy, f, ay);
-        az = fmaf(dz, f, az);
-        resume = take ? nd.next : resume;
-        const unsigned long long any_open = m_active & ~m_geom;
-        const int seq = c + 1;
-        const int nxt_c = nd.next > seq ? nd.next : seq;
-        if (kCount) {
-            wv += 1;
-            lv += active ? 1 : 0;
-            la += (take && dist_sq > P.eps2) ? 1 : 0;
+#define NBMI_VISIT(k)                                                                                        \
+    do {                                                                                                     \
+        bool a_, f_, j_;                                                                                     \
+        const int c_old = c[k];                                                                              \
+        c[k] = visit<kGuard>(nodes, c[k], px[k], py[k], pz[k], P.eps2, resume[k], ax[k], ay[k], az[k], a_, f_, j_); \
+        if (kCount) {                                                                                        \
+            wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0;                                   \
+            if (k == 0) {                                                                                    \
+                _Pragma("unroll") for (int w = 0; w < 4; w++) {                                              \
+                    if (c_old < wbase[w] || c_old >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c_old; }     \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    } while (0)
+
+    if (kCur == 1) {
+        while (c[0] < nn) NBMI_VISIT(0);
+    } else if (kCur == 2) {
+        while (c[0] < nn && c[1] < nn) { NBMI_VISIT(0); NBMI_VISIT(1); }
+        while (c[0] < nn) NBMI_VISIT(0);
+        while (c[1] < nn) NBMI_VISIT(1);
+    } else {
+        // all cursors while all are live, then drain each one
+        for (;;) {
+            bool all = true;
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                if (c < wbase[w] || c >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c; }
-            }
-            jm += (!any_open && nxt_c != seq) ? 1 : 0;
+            for (int k = 0; k < kCur; k++) all = all && (c[k] < nn);
+            if (!all) break;
+#pragma unroll
+            for (int k = 0; k < kCur; k++) NBMI_VISIT(k);
         }
-        c = any_open ? seq : nxt_c;
+#pragma unroll
+        for (int k = 0; k < kCur; k++) {
+            while (c[k] < nn) NBMI_VISIT(k);
+        }
     }
+#undef NBMI_VISIT
 
     if (kCount) {
         // wave_visits counted once per wave (lane 0), lane counters summed over lanes
-        if ((threadIdx.x & 63) == 0) {
+        if (lane == 0) {
             atomicAdd(&info_out->wave_visits, wv);
             for (int w = 0; w < 4; w++) atomicAdd(&info_out->win_miss[w], wm[w]);
             atomicAdd(&info_out->jumps, jm);
@@ -387,23 +435,27 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         atomicAdd(&info_out->lane_visits, lv);
         atomicAdd(&info_out->lane_accepts, la);
     }
-    if (!valid) return;
-    const uint32_t j = perm[rank];
-    if (kIntegrate) {
-        double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
-        const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
-        const int32_t id0 = cur.id[j];
-        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
-        vx *= P.damping; vy *= P.damping; vz *= P.damping;
-        nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
-        nxt.x[rank] = x0 + vx * P.dt;
-        nxt.y[rank] = y0 + vy * P.dt;
-        nxt.z[rank] = z0 + vz * P.dt;
-        nxt.m[rank] = m0;
-        nxt.id[rank] = id0;
-    } else {
-        const int64_t o = 3 * (int64_t)cur.id[j];
-        acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
+#pragma unroll
+    for (int k = 0; k < kCur; k++) {
+        if (!valid[k]) continue;
+        const int64_t rank = base + (int64_t)k * 64;
+        const uint32_t j = perm[rank];
+        if (kIntegrate) {
+            double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+            const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
+            const int32_t id0 = cur.id[j];
+            vx += (double)ax[k] * P.dt; vy += (double)ay[k] * P.dt; vz += (double)az[k] * P.dt;
+            vx *= P.damping; vy *= P.damping; vz *= P.damping;
+            nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
+            nxt.x[rank] = x0 + vx * P.dt;
+            nxt.y[rank] = y0 + vy * P.dt;
+            nxt.z[rank] = z0 + vz * P.dt;
+            nxt.m[rank] = m0;
+            nxt.id[rank] = id0;
+        } else {
+            const int64_t o = 3 * (int64_t)cur.id[j];
+            acc_out[o] = (double)ax[k]; acc_out[o + 1] = (double)ay[k]; acc_out[o + 2] = (double)az[k];
+        }
     }
 }
 
@@ -632,6 +684,9 @@ struct nbmi_sim {
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
     bool count_walk = false;
+    int walk_cursors = 1;  // independent cursors (64-body groups) per wave: 1, 2 or 4
+    int xcd_remap = 1;     // give each XCD a contiguous chunk of body groups
+    int walk_block = 256;  // threads per walk block (64, 128 or 256)
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {};
@@ -715,13 +770,25 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.damping = s->damping;
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
-    const int gb = nblocks(cntr);
-#define NBMI_WALK(I, C, G) \
-    k_walk<I, C, G><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
+    P.xcd_remap = s->xcd_remap;
+    const int ncur = integrate ? s->walk_cursors : 1;  // the counted (parity) walk is single-cursor
+    const int wb = s->walk_block;
+    const int64_t per_block = (int64_t)wb * ncur;
+    const int gb = (int)((cntr + per_block - 1) / per_block);
+#define NBMI_WALK(I, C, G, K) \
+    k_walk<I, C, G, K><<<gb, wb, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
     if (integrate) {
-        if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
+        if (guard) {
+            if (ncur == 4) NBMI_WALK(true, false, true, 4);
+            else if (ncur == 2) NBMI_WALK(true, false, true, 2);
+            else NBMI_WALK(true, false, true, 1);
+        } else {
+            if (ncur == 4) NBMI_WALK(true, false, false, 4);
+            else if (ncur == 2) NBMI_WALK(true, false, false, 2);
+            else NBMI_WALK(true, false, false, 1);
+        }
     } else {
-        if (guard) NBMI_WALK(false, true, true); else NBMI_WALK(false, true, false);
+        if (guard) NBMI_WALK(false, true, true, 1); else NBMI_WALK(false, true, false, 1);
     }
 #undef NBMI_WALK
     NBMI_HIP_CHECK(hipGetLastError());
@@ -867,6 +934,15 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     nbmi_sim *s = new nbmi_sim();
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
+    if (const char *e = getenv("NBMI_WALK_CURSORS")) {  // tuning knobs (measurement only)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) s->walk_cursors = v;
+    }
+    if (const char *e = getenv("NBMI_XCD_REMAP")) s->xcd_remap = atoi(e) != 0;
+    if (const char *e = getenv("NBMI_WALK_BLOCK")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256) s->walk_block = v;
+    }
     if (create_impl(s, pos, vel, mass) != 0) {
         std::string keep = nbmi::get_error();
         nbmi_destroy(s);

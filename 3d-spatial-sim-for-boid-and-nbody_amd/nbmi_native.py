@@ -5,6 +5,7 @@ and if no HIP device is present the constructors raise RuntimeError.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnbmi.so")
@@ -56,11 +57,28 @@ PROTOTYPES = {
 }
 
 
+def _torch_first():
+    """PyTorch-ROCm wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so +
+    libhsa-runtime64.so.1, same SONAME as /opt/rocm's newer one).  The two coexist in one
+    process only if torch's runtime comes up FIRST; if libnbmi.so initialises the system runtime
+    first, a later torch.cuda init reports "No HIP GPUs are available".  So: when torch is
+    already imported, make it initialise before libnbmi.so is mapped.  Programs that need both
+    (bench.py, nbody/sharded.py) import torch first; programs that never import torch are
+    unaffected."""
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            torch.cuda.is_available()
+        except Exception:
+            pass
+
+
 def load():
     """Load libnbmi.so (once).  Raises ImportError with build instructions if it is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    _torch_first()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built. "
