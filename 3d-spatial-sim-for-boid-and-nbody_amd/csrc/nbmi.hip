@@ -57,13 +57,15 @@ constexpr int kMaxLevel = 42;  // key digits available (2 x 21)
 
 // 32-byte octree node, DFS pre-order.  Loaded with one scalar s_load_dwordx8 per visit.
 struct alignas(32) Node {
-    float cx, cy, cz;  // centre of mass (leaf: the body's position)
-    float gm;          // G * mass
-    float s2t;         // (2*half_size)^2 / theta^2 (accept when s2t < dist_sq); 0 for leaves
-    int next;          // index of the first node after this node's subtree
-    int ref;           // leaf: sorted rank of its body (>= 0); internal: ~(rank of first body)
-    int level;         // depth, root = 0
+    float cx, cy, cz;   // centre of mass (leaf: the body's position)
+    float gm;           // G * mass
+    float s2t;          // (2*half_size)^2 / theta^2 (accept when s2t < dist_sq); 0 for leaves
+    unsigned next_off;  // BYTE offset (index * 32) of the first node after this node's subtree
+    unsigned seq_off;   // byte offset of the node that follows this one in memory (own offset + 32)
+    int ref;            // leaf: sorted rank of its body (>= 0); internal: ~(rank of first body)
 };
+// Node `num_nodes` is a sentinel that loops onto itself (next = seq = own offset, zero mass, at
+// "infinity"): the unrolled walk may step onto it a few times after the traversal has ended.
 static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
 struct Bodies {
@@ -91,12 +93,22 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-// XCD-aware block remap: hardware deals consecutive blocks round-robin over the 8 XCDs, so give
-// XCD k a contiguous chunk of logical blocks (neighbouring body groups then share one L2).
-__device__ __forceinline__ int logical_block(int b, int nb) {
-    const int q = nb >> 3, rem = nb & 7;
-    const int xcd = b & 7, local = b >> 3;
-    return xcd * q + (xcd < rem ? xcd : rem) + local;
+// XCD-aware block remap.  Hardware deals consecutive blocks round-robin over the 8 XCDs (blocks b
+// and b+8 share an XCD and its L2).  Neighbouring body groups walk nearly the same nodes, so every
+// XCD should get CONTIGUOUS runs of logical blocks; runs of `chunk` blocks are interleaved over
+// the XCDs so that dense and sparse regions of the key order are spread evenly (chunk = 0: one
+// contiguous eighth per XCD; chunk < 0: identity).  Speed only, never correctness.
+__device__ __forceinline__ int logical_block(int b, int nb, int chunk) {
+    if (chunk < 0) return b;
+    const int xcd = b & 7, j = b >> 3;
+    if (chunk == 0) {
+        const int q = nb >> 3, rem = nb & 7;
+        return xcd * q + (xcd < rem ? xcd : rem) + j;
+    }
+    const int span = 8 * chunk;
+    const int full = (nb / span) * span;  // blocks covered by complete rounds of 8 chunks
+    if (b >= full) return b;
+    return ((j / chunk) * 8 + xcd) * chunk + (j % chunk);
 }
 
 __device__ __forceinline__ int cpl_digits(uint64_t ahi, uint64_t alo, uint64_t bhi, uint64_t blo) {
@@ -236,7 +248,8 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
                                                  const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
                                                  const Moment *__restrict__ S, const float4 *__restrict__ posm_s,
                                                  int64_t n, double G, double inv_theta2, int64_t capacity,
-                                                 Node *__restrict__ nodes, TreeInfo *info) {
+                                                 Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
+                                                 TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const double bounds = info->bounds;
@@ -244,10 +257,19 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
     const int dp = r > 0 ? delta[r - 1] : -1;
     const int cnt = d > dp ? d - dp : 0;
     const int64_t base = r + (int64_t)Pex[r];
-    if (r == 0) info->num_nodes = n + (long long)Pex[n];
-    if (base + cnt >= capacity) {
+    const int64_t total = n + (int64_t)Pex[n];
+    if (r == 0) info->num_nodes = total;
+    if (total + 1 > capacity) {  // + 1: the sentinel
         info->error = 1;
         return;
+    }
+    if (r == 0) {
+        Node sn;
+        sn.cx = sn.cy = sn.cz = 1.0e30f;
+        sn.gm = 0.f; sn.s2t = 0.f;
+        sn.next_off = sn.seq_off = (unsigned)(total << 5);
+        sn.ref = -1;
+        nodes[total] = sn;
     }
     const uint64_t h = hi_s[r], l = lo_s[r];
     const Moment s0 = S[r];
@@ -280,20 +302,21 @@ __global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi
         nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
         nd.gm = (float)(G * M);
         nd.s2t = (float)(size * size * inv_theta2);
-        nd.next = (int)(e + (int64_t)Pex[e]);
+        nd.next_off = (unsigned)((e + (int64_t)Pex[e]) << 5);
+        nd.seq_off = (unsigned)((base + k + 1) << 5);
         nd.ref = ~(int)r;
-        nd.level = lev;
         nodes[base + k] = nd;
+        node_level[base + k] = (uint8_t)lev;
     }
     const float4 p = posm_s[r];
     const int leaf_level = (d > dp ? d : dp) + 1;
     Node lf;
     lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
     lf.s2t = 0.0f;
-    lf.next = (int)(base + cnt + 1);
+    lf.next_off = lf.seq_off = (unsigned)((base + cnt + 1) << 5);
     lf.ref = (int)r;
-    lf.level = leaf_level;
     nodes[base + cnt] = lf;
+    node_level[base + cnt] = (uint8_t)leaf_level;
     atomicMax(&info->max_level, leaf_level);
 }
 
@@ -315,23 +338,22 @@ struct WalkParams {
     int64_t n;
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
     float eps2;
-    int xcd_remap;
+    int xcd_chunk;  // see logical_block()
     double dt, damping;
 };
 
-// One node visit of cursor `c` for the lane's body (px,py,pz): returns the next cursor value.
+// One node visit (C++ form; the counted / eps == 0 kernels use it).  `off` is the cursor as a byte
+// offset into the node array; `resume` likewise.  Returns the next cursor.
 template <bool kGuard>
-__device__ __forceinline__ int visit(const Node *__restrict__ nodes, int c, float px, float py, float pz, float eps2,
-                                     int &resume, float &ax, float &ay, float &az, bool &active_out,
-                                     bool &force_out, bool &jumped) {
-    c = __builtin_amdgcn_readfirstlane(c);
-    // byte offset as an unsigned 32-bit scalar: s_load with an SGPR offset, no 64-bit address maths
-    const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + ((unsigned)c << 5));
+__device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsigned off, float px, float py, float pz,
+                                          float eps2, unsigned &resume, float &ax, float &ay, float &az,
+                                          bool &active_out, bool &force_out, bool &jumped) {
+    off = __builtin_amdgcn_readfirstlane(off);
+    const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
     const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
     const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
-    const bool active = resume <= c;
-    // both operands are non-negative floats: compare their bit patterns as integers (the
-    // compiler folds an integer compare straight into the ballot's lane mask)
+    const bool active = resume <= off;
+    // both operands are non-negative floats: compare their bit patterns as integers
     const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
     const unsigned long long m_active = __builtin_amdgcn_ballot_w64(active);
     const unsigned long long m_geom = __builtin_amdgcn_ballot_w64(geom);
@@ -343,119 +365,123 @@ __device__ __forceinline__ int visit(const Node *__restrict__ nodes, int c, floa
     ax = fmaf(dx, f, ax);
     ay = fmaf(dy, f, ay);
     az = fmaf(dz, f, az);
-    resume = take ? nd.next : resume;
+    resume = take ? nd.next_off : resume;
     const unsigned long long any_open = m_active & ~m_geom;
-    const int seq = c + 1;
-    const int nxt_c = nd.next;  // k_emit guarantees next > c; a flagged (overflowed) build is never walked
     active_out = active;
     force_out = take && (dist_sq > eps2);
-    jumped = !any_open && nxt_c != seq;
-    return any_open ? seq : nxt_c;
+    jumped = !any_open && nd.next_off != nd.seq_off;
+    return any_open ? nd.seq_off : nd.next_off;
 }
 
-// kCur independent cursors per wave: lane l carries the bodies of ranks base + k*64 + l
-// (k < kCur), i.e. kCur adjacent 64-body groups, each walked by its own wave-uniform cursor.
-// The chains are independent, so their scalar-load latencies overlap (the single-cursor walk is
-// bound by the load -> compare -> branch dependency of one wave, not by VALU issue).
-template <bool kIntegrate, bool kCount, bool kGuard, int kCur>
+// Hand-scheduled visit for the product kernel (eps > 0, no counters): 17 VALU + 5 scalar
+// instructions.  Scalar issue is the scarce resource on gfx950 (one slot per SIMD every ~4 cycles,
+// scripts/ubench/issue_rate.hip), so: one s_load_dwordx8 at an SGPR byte offset, s_andn2 leaves
+// "any lane opens" in SCC for the s_cselect that picks seq_off / next_off, `take` goes to VCC for
+// the two selects.  Node dwords land in s[36:43]: cx cy cz gm s2t next_off seq_off ref.
+#define NBMI_VISIT_ASM                                         \
+    "s_load_dwordx8 s[36:43], %[base], %[off]\n"               \
+    "s_waitcnt lgkmcnt(0)\n"                                   \
+    "v_cmp_ge_u32_e64 s[44:45], %[off], %[resume]\n"           \
+    "v_sub_f32_e32 %[dx], s36, %[px]\n"                        \
+    "v_sub_f32_e32 %[dy], s37, %[py]\n"                        \
+    "v_sub_f32_e32 %[dz], s38, %[pz]\n"                        \
+    "v_fma_f32 %[d2], %[dx], %[dx], %[eps2]\n"                 \
+    "v_fmac_f32_e32 %[d2], %[dy], %[dy]\n"                     \
+    "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
+    "v_cmp_lt_i32_e64 s[46:47], s40, %[d2]\n"                  \
+    "v_rsq_f32_e32 %[inv], %[d2]\n"                            \
+    "s_and_b64 vcc, s[44:45], s[46:47]\n"                      \
+    "s_andn2_b64 s[44:45], s[44:45], s[46:47]\n"               \
+    "s_cselect_b32 %[off], s42, s41\n"                         \
+    "v_mul_f32_e32 %[f], s39, %[inv]\n"                        \
+    "v_mul_f32_e32 %[t], %[inv], %[inv]\n"                     \
+    "v_mul_f32_e32 %[f], %[f], %[t]\n"                         \
+    "v_mov_b32_e32 %[t], s41\n"                                \
+    "v_cndmask_b32_e32 %[resume], %[resume], %[t], vcc\n"      \
+    "v_cndmask_b32_e32 %[f], 0, %[f], vcc\n"                   \
+    "v_fmac_f32_e32 %[ax], %[dx], %[f]\n"                      \
+    "v_fmac_f32_e32 %[ay], %[dy], %[f]\n"                      \
+    "v_fmac_f32_e32 %[az], %[dz], %[f]\n"
+
+__device__ __forceinline__ void visit4_asm(const Node *nodes, unsigned &off, float px, float py, float pz, float eps2,
+                                           unsigned &resume, float &ax, float &ay, float &az) {
+    float dx, dy, dz, d2, inv, f, t;
+    asm volatile(NBMI_VISIT_ASM NBMI_VISIT_ASM NBMI_VISIT_ASM NBMI_VISIT_ASM
+                 : [off] "+s"(off), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv), [f] "=&v"(f),
+                   [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "vcc", "scc");
+}
+
+// The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
+// otherwise the hand-scheduled loop (eps > 0) or the C++ visit with the distance guard (eps == 0).
+template <bool kIntegrate, bool kCount, bool kGuard>
 __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const TreeInfo *info_in,
                                                  const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
                                                  Bodies cur, Bodies nxt, double *__restrict__ acc_out, WalkParams P,
                                                  TreeInfo *info_out) {
-    const int lb = P.xcd_remap ? logical_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t base = P.rank_begin + ((int64_t)lb * (blockDim.x >> 6) + wave) * (64 * kCur) + lane;
-    const int nn = (info_in->error != 0) ? 0 : (int)info_in->num_nodes;
+    const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    const int lane = threadIdx.x & 63;
+    const int64_t rank = P.rank_begin + (int64_t)lb * kBlock + threadIdx.x;
+    const bool valid = rank < P.rank_end;
+    const unsigned nn = (info_in->error != 0) ? 0u : ((unsigned)info_in->num_nodes << 5);  // end offset
 
-    float px[kCur], py[kCur], pz[kCur], ax[kCur], ay[kCur], az[kCur];
-    int resume[kCur], c[kCur];
-    bool valid[kCur];
-#pragma unroll
-    for (int k = 0; k < kCur; k++) {
-        const int64_t rank = base + (int64_t)k * 64;
-        valid[k] = rank < P.rank_end;
-        px[k] = py[k] = pz[k] = 0.f;
-        if (valid[k]) {
-            const float4 p = posm_s[rank];
-            px[k] = p.x; py[k] = p.y; pz[k] = p.z;
-        }
-        resume[k] = valid[k] ? 0 : 0x7fffffff;
-        ax[k] = ay[k] = az[k] = 0.f;
-        c[k] = 0;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+        const float4 p = posm_s[rank];
+        px = p.x; py = p.y; pz = p.z;
     }
-    unsigned long long wv = 0, lv = 0, la = 0;
-    unsigned long long wm[4] = {0, 0, 0, 0}, jm = 0;
-    int wbase[4] = {-1000, -1000, -1000, -1000};
+    unsigned resume = valid ? 0u : 0xffffffffu;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned off = 0u;
 
-#define NBMI_VISIT(k)                                                                                        \
-    do {                                                                                                     \
-        bool a_, f_, j_;                                                                                     \
-        const int c_old = c[k];                                                                              \
-        c[k] = visit<kGuard>(nodes, c[k], px[k], py[k], pz[k], P.eps2, resume[k], ax[k], ay[k], az[k], a_, f_, j_); \
-        if (kCount) {                                                                                        \
-            wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0;                                   \
-            if (k == 0) {                                                                                    \
-                _Pragma("unroll") for (int w = 0; w < 4; w++) {                                              \
-                    if (c_old < wbase[w] || c_old >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c_old; }     \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-    } while (0)
-
-    if (kCur == 1) {
-        while (c[0] < nn) NBMI_VISIT(0);
-    } else if (kCur == 2) {
-        while (c[0] < nn && c[1] < nn) { NBMI_VISIT(0); NBMI_VISIT(1); }
-        while (c[0] < nn) NBMI_VISIT(0);
-        while (c[1] < nn) NBMI_VISIT(1);
+    if (!kCount && !kGuard) {
+        while (off < nn) visit4_asm(nodes, off, px, py, pz, P.eps2, resume, ax, ay, az);
     } else {
-        // all cursors while all are live, then drain each one
-        for (;;) {
-            bool all = true;
+        unsigned long long wv = 0, lv = 0, la = 0, jm = 0;
+        unsigned long long wm[4] = {0, 0, 0, 0};
+        int wbase[4] = {-1000, -1000, -1000, -1000};
+        while (off < nn) {
+            bool a_, f_, j_;
+            const int c_old = (int)(off >> 5);
+            off = visit<kGuard>(nodes, off, px, py, pz, P.eps2, resume, ax, ay, az, a_, f_, j_);
+            if (kCount) {
+                wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0;
 #pragma unroll
-            for (int k = 0; k < kCur; k++) all = all && (c[k] < nn);
-            if (!all) break;
-#pragma unroll
-            for (int k = 0; k < kCur; k++) NBMI_VISIT(k);
+                for (int w = 0; w < 4; w++) {
+                    if (c_old < wbase[w] || c_old >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c_old; }
+                }
+            }
         }
-#pragma unroll
-        for (int k = 0; k < kCur; k++) {
-            while (c[k] < nn) NBMI_VISIT(k);
+        if (kCount) {
+            // wave_visits counted once per wave (lane 0), lane counters summed over lanes
+            if (lane == 0) {
+                atomicAdd(&info_out->wave_visits, wv);
+                for (int w = 0; w < 4; w++) atomicAdd(&info_out->win_miss[w], wm[w]);
+                atomicAdd(&info_out->jumps, jm);
+            }
+            atomicAdd(&info_out->lane_visits, lv);
+            atomicAdd(&info_out->lane_accepts, la);
         }
     }
-#undef NBMI_VISIT
-
-    if (kCount) {
-        // wave_visits counted once per wave (lane 0), lane counters summed over lanes
-        if (lane == 0) {
-            atomicAdd(&info_out->wave_visits, wv);
-            for (int w = 0; w < 4; w++) atomicAdd(&info_out->win_miss[w], wm[w]);
-            atomicAdd(&info_out->jumps, jm);
-        }
-        atomicAdd(&info_out->lane_visits, lv);
-        atomicAdd(&info_out->lane_accepts, la);
-    }
-#pragma unroll
-    for (int k = 0; k < kCur; k++) {
-        if (!valid[k]) continue;
-        const int64_t rank = base + (int64_t)k * 64;
-        const uint32_t j = perm[rank];
-        if (kIntegrate) {
-            double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
-            const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
-            const int32_t id0 = cur.id[j];
-            vx += (double)ax[k] * P.dt; vy += (double)ay[k] * P.dt; vz += (double)az[k] * P.dt;
-            vx *= P.damping; vy *= P.damping; vz *= P.damping;
-            nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
-            nxt.x[rank] = x0 + vx * P.dt;
-            nxt.y[rank] = y0 + vy * P.dt;
-            nxt.z[rank] = z0 + vz * P.dt;
-            nxt.m[rank] = m0;
-            nxt.id[rank] = id0;
-        } else {
-            const int64_t o = 3 * (int64_t)cur.id[j];
-            acc_out[o] = (double)ax[k]; acc_out[o + 1] = (double)ay[k]; acc_out[o + 2] = (double)az[k];
-        }
+    if (!valid) return;
+    const uint32_t j = perm[rank];
+    if (kIntegrate) {
+        double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+        const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
+        const int32_t id0 = cur.id[j];
+        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
+        vx *= P.damping; vy *= P.damping; vz *= P.damping;
+        nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
+        nxt.x[rank] = x0 + vx * P.dt;
+        nxt.y[rank] = y0 + vy * P.dt;
+        nxt.z[rank] = z0 + vz * P.dt;
+        nxt.m[rank] = m0;
+        nxt.id[rank] = id0;
+    } else {
+        const int64_t o = 3 * (int64_t)cur.id[j];
+        acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
     }
 }
 
@@ -627,14 +653,16 @@ __global__ __launch_bounds__(kBlock) void k_keys_to_orig(const uint64_t *__restr
     out_hi[o] = hi_s[r];
     out_lo[o] = lo_s[r];
 }
-__global__ __launch_bounds__(kBlock) void k_cells(const Node *__restrict__ nodes, const uint64_t *__restrict__ hi_s,
-                                                  int64_t num_nodes, int32_t *__restrict__ level, uint64_t *__restrict__ key) {
+__global__ __launch_bounds__(kBlock) void k_cells(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
+                                                  const uint64_t *__restrict__ hi_s, int64_t num_nodes,
+                                                  int32_t *__restrict__ level, uint64_t *__restrict__ key) {
     const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (u >= num_nodes) return;
     const Node nd = nodes[u];
     const int r = nd.ref >= 0 ? nd.ref : ~nd.ref;
-    level[u] = nd.level;
-    key[u] = nd.level <= 21 ? (nd.level == 0 ? 0ull : (hi_s[r] >> (63 - 3 * nd.level))) : ~0ull;
+    const int lev = node_level[u];
+    level[u] = lev;
+    key[u] = lev <= 21 ? (lev == 0 ? 0ull : (hi_s[r] >> (63 - 3 * lev))) : ~0ull;
 }
 // multi-GPU row pack / unpack: {x,y,z,vx,vy,vz,m,id}
 __global__ __launch_bounds__(kBlock) void k_pack_rows(Bodies cur, int64_t begin, int64_t end, double *__restrict__ rows) {
@@ -675,6 +703,7 @@ struct nbmi_sim {
     float4 *posm_s = nullptr;
     Moment *W = nullptr, *S = nullptr;
     Node *nodes = nullptr;
+    uint8_t *node_level = nullptr;
     int64_t node_capacity = 0;
     TreeInfo *info = nullptr;  // device
     void *tmp_sort = nullptr, *tmp_scan_i = nullptr, *tmp_scan_m = nullptr;
@@ -684,9 +713,7 @@ struct nbmi_sim {
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
     bool count_walk = false;
-    int walk_cursors = 1;  // independent cursors (64-body groups) per wave: 1, 2 or 4
-    int xcd_remap = 1;     // give each XCD a contiguous chunk of body groups
-    int walk_block = 256;  // threads per walk block (64, 128 or 256)
+    int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {};
@@ -749,7 +776,7 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->delta, s->Pex, s->S, s->posm_s, n, s->G, inv_theta2,
-                                          s->node_capacity, s->nodes, s->info);
+                                          s->node_capacity, s->nodes, s->node_level, s->info);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], st));
     NBMI_HIP_CHECK(hipGetLastError());
     s->tree_valid = true;
@@ -770,25 +797,14 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.damping = s->damping;
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
-    P.xcd_remap = s->xcd_remap;
-    const int ncur = integrate ? s->walk_cursors : 1;  // the counted (parity) walk is single-cursor
-    const int wb = s->walk_block;
-    const int64_t per_block = (int64_t)wb * ncur;
-    const int gb = (int)((cntr + per_block - 1) / per_block);
-#define NBMI_WALK(I, C, G, K) \
-    k_walk<I, C, G, K><<<gb, wb, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
+    P.xcd_chunk = s->xcd_chunk;
+    const int gb = nblocks(cntr);
+#define NBMI_WALK(I, C, G) \
+    k_walk<I, C, G><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
     if (integrate) {
-        if (guard) {
-            if (ncur == 4) NBMI_WALK(true, false, true, 4);
-            else if (ncur == 2) NBMI_WALK(true, false, true, 2);
-            else NBMI_WALK(true, false, true, 1);
-        } else {
-            if (ncur == 4) NBMI_WALK(true, false, false, 4);
-            else if (ncur == 2) NBMI_WALK(true, false, false, 2);
-            else NBMI_WALK(true, false, false, 1);
-        }
+        if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
     } else {
-        if (guard) NBMI_WALK(false, true, true, 1); else NBMI_WALK(false, true, false, 1);
+        if (guard) NBMI_WALK(false, true, true); else NBMI_WALK(false, true, false);
     }
 #undef NBMI_WALK
     NBMI_HIP_CHECK(hipGetLastError());
@@ -879,7 +895,8 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
-            dev_alloc(s, &s->W, n + 1) || dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->nodes, s->node_capacity))
+            dev_alloc(s, &s->W, n + 1) || dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->nodes, s->node_capacity) ||
+            dev_alloc(s, &s->node_level, s->node_capacity))
             return -2;
         s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
         s->tmp_scan_i_bytes = nbmi::scan_i32_temp_bytes((size_t)n + 1);
@@ -910,7 +927,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
 nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const double *mass, double G,
                       double softening, double damping, double theta, int method, int device) {
     nbmi::clear_error();
-    if (n < 0 || n > 400000000 || (n > 0 && (!pos || !vel || !mass))) {
+    if (n < 0 || n > 30000000 || (n > 0 && (!pos || !vel || !mass))) {
         nbmi::set_error("nbmi_create: bad arguments (n=%lld)", (long long)n);
         return nullptr;
     }
@@ -934,15 +951,7 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     nbmi_sim *s = new nbmi_sim();
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
-    if (const char *e = getenv("NBMI_WALK_CURSORS")) {  // tuning knobs (measurement only)
-        const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) s->walk_cursors = v;
-    }
-    if (const char *e = getenv("NBMI_XCD_REMAP")) s->xcd_remap = atoi(e) != 0;
-    if (const char *e = getenv("NBMI_WALK_BLOCK")) {
-        const int v = atoi(e);
-        if (v == 64 || v == 128 || v == 256) s->walk_block = v;
-    }
+    if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);  // tuning knob (measurement only)
     if (create_impl(s, pos, vel, mass) != 0) {
         std::string keep = nbmi::get_error();
         nbmi_destroy(s);
@@ -1150,7 +1159,7 @@ int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity)
     uint64_t *dk = nullptr;
     NBMI_HIP_CHECK(hipMalloc((void **)&dl, (size_t)nn * 4));
     NBMI_HIP_CHECK(hipMalloc((void **)&dk, (size_t)nn * 8));
-    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->hi_s, nn, dl, dk);
+    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->node_level, s->hi_s, nn, dl, dk);
     hipError_t e1 = hipMemcpyAsync(level, dl, (size_t)nn * 4, hipMemcpyDeviceToHost, s->stream);
     hipError_t e2 = hipMemcpyAsync(key, dk, (size_t)nn * 8, hipMemcpyDeviceToHost, s->stream);
     hipError_t e3 = hipStreamSynchronize(s->stream);

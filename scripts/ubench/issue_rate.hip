@@ -1,83 +1,85 @@
-// Micro-benchmark: VALU / SALU issue rates on gfx950 with 8 waves per SIMD.
+// Micro-benchmark: VALU / SALU / SMEM issue behaviour on gfx950 (inline asm so that the compiler
+// cannot re-pack or delete anything).  Prints cycles per loop iteration per SIMD.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#define ITER 4096
-typedef float float2v __attribute__((ext_vector_type(2)));
+#define ITER 2048
+#define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-__global__ __launch_bounds__(256) void k_fma(float *out, float a, float b) {
-    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
-    for (int i = 0; i < ITER; i++) {
-        x0 = fmaf(x0, a, b); x1 = fmaf(x1, a, b); x2 = fmaf(x2, a, b); x3 = fmaf(x3, a, b);
-        x0 = fmaf(x0, a, b); x1 = fmaf(x1, a, b); x2 = fmaf(x2, a, b); x3 = fmaf(x3, a, b);
-    }
+#define V4 "v_fma_f32 %0, %0, %5, %6\n v_fma_f32 %1, %1, %5, %6\n v_fma_f32 %2, %2, %5, %6\n v_fma_f32 %3, %3, %5, %6\n"
+#define S4 "s_add_u32 %4, %4, 7\n s_xor_b32 %4, %4, 0x55\n s_lshl_b32 %4, %4, 1\n s_lshr_b32 %4, %4, 1\n"
+#define P2 "v_pk_fma_f32 %0, %0, %2, %3\n v_pk_fma_f32 %1, %1, %2, %3\n"
+
+// 16 plain VALU per iteration
+__global__ __launch_bounds__(256) void k_v16(float *out, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    for (int i = 0; i < ITER; i++)
+        asm volatile(V4 V4 V4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
 }
-__global__ __launch_bounds__(256) void k_pkfma(float *out, float a, float b) {
-    float2v x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
-    float2v av = {a, a}, bv = {b, b};
-    for (int i = 0; i < ITER; i++) {
-        x0 = __builtin_elementwise_fma(x0, av, bv); x1 = __builtin_elementwise_fma(x1, av, bv);
-        x2 = __builtin_elementwise_fma(x2, av, bv); x3 = __builtin_elementwise_fma(x3, av, bv);
-        x0 = __builtin_elementwise_fma(x0, av, bv); x1 = __builtin_elementwise_fma(x1, av, bv);
-        x2 = __builtin_elementwise_fma(x2, av, bv); x3 = __builtin_elementwise_fma(x3, av, bv);
-    }
-    float2v s = x0 + x1 + x2 + x3;
-    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
-}
-// 8 VALU + 8 SALU per iteration (scalar work on a uniform value)
-__global__ __launch_bounds__(256) void k_mix(float *out, float a, float b, unsigned seed) {
-    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
-    unsigned s = seed;
-    for (int i = 0; i < ITER; i++) {
-        x0 = fmaf(x0, a, b); x1 = fmaf(x1, a, b); x2 = fmaf(x2, a, b); x3 = fmaf(x3, a, b);
-        x0 = fmaf(x0, a, b); x1 = fmaf(x1, a, b); x2 = fmaf(x2, a, b); x3 = fmaf(x3, a, b);
-        asm volatile("s_add_u32 %0, %0, 7\n s_xor_b32 %0, %0, 0x55\n s_lshl_b32 %0, %0, 1\n s_add_u32 %0, %0, 3\n"
-                     "s_xor_b32 %0, %0, 0x33\n s_lshr_b32 %0, %0, 1\n s_add_u32 %0, %0, 5\n s_xor_b32 %0, %0, 0x0f\n"
-                     : "+s"(s));
-    }
+// 16 VALU + 12 SALU per iteration (interleaved)
+__global__ __launch_bounds__(256) void k_v16s12(float *out, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    for (int i = 0; i < ITER; i++)
+        asm volatile(V4 S4 V4 S4 V4 S4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + (float)s;
 }
-// 8 SALU only
-__global__ __launch_bounds__(256) void k_salu(float *out, unsigned seed) {
-    unsigned s = seed;
-    for (int i = 0; i < ITER; i++) {
-        asm volatile("s_add_u32 %0, %0, 7\n s_xor_b32 %0, %0, 0x55\n s_lshl_b32 %0, %0, 1\n s_add_u32 %0, %0, 3\n"
-                     "s_xor_b32 %0, %0, 0x33\n s_lshr_b32 %0, %0, 1\n s_add_u32 %0, %0, 5\n s_xor_b32 %0, %0, 0x0f\n"
-                     : "+s"(s));
-    }
-    out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+// 12 SALU only
+__global__ __launch_bounds__(256) void k_s12(float *out, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    for (int i = 0; i < ITER; i++)
+        asm volatile(S4 S4 S4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + (float)s;
 }
-// rsq + cmp + cndmask mix like the walk
-__global__ __launch_bounds__(256) void k_rsq(float *out, float a) {
-    float x0 = threadIdx.x + 1.f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+// 8 packed fma
+typedef float float2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_pk8(float *out, float a, float b) {
+    float2v x0 = {(float)threadIdx.x, 1.f}, x1 = {2.f, 3.f}, av = {a, a}, bv = {b, b};
+    for (int i = 0; i < ITER; i++)
+        asm volatile(P2 P2 P2 P2 : "+v"(x0), "+v"(x1) : "v"(av), "v"(bv));
+    out[blockIdx.x * 256 + threadIdx.x] = x0.x + x0.y + x1.x + x1.y;
+}
+// dependent scalar-load chain (pointer chase through a ring of 32-byte records) + 16 VALU + 12 SALU
+__global__ __launch_bounds__(256) void k_chase(float *out, const int *__restrict__ ring, float a, float b, int mask) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    int c = (blockIdx.x * 4 + (threadIdx.x >> 6)) & mask;
     for (int i = 0; i < ITER; i++) {
-        x0 = __builtin_amdgcn_rsqf(x0) + a; x1 = __builtin_amdgcn_rsqf(x1) + a;
-        x2 = __builtin_amdgcn_rsqf(x2) + a; x3 = __builtin_amdgcn_rsqf(x3) + a;
+        c = __builtin_amdgcn_readfirstlane(c);
+        c = ring[c * 8];  // scalar load, next index
+        asm volatile(V4 S4 V4 S4 V4 S4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
     }
-    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3;
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + (float)s + c;
 }
 template <typename F>
 float timeit(F f) {
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    f(); hipDeviceSynchronize();
-    hipEventRecord(a); for (int i = 0; i < 5; i++) f(); hipEventRecord(b); hipEventSynchronize(b);
-    float ms; hipEventElapsedTime(&ms, a, b); return ms / 5;
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    f(); (void)hipDeviceSynchronize();
+    (void)hipEventRecord(a); for (int i = 0; i < 5; i++) f(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); return ms / 5;
 }
 int main() {
-    float *out; hipMalloc(&out, 256 * 8 * 256 * 4 * sizeof(float));
-    for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD = blocks per CU (256-thread blocks = 1 wave per SIMD)
-        int grid = 256 * wps;
-        double waves_per_simd = wps;
-        double simd_instr = (double)ITER * 8 * waves_per_simd;  // per SIMD
-        float t1 = timeit([&] { k_fma<<<grid, 256>>>(out, 1.0001f, 0.5f); });
-        float t2 = timeit([&] { k_pkfma<<<grid, 256>>>(out, 1.0001f, 0.5f); });
-        float t3 = timeit([&] { k_mix<<<grid, 256>>>(out, 1.0001f, 0.5f, 1u); });
-        float t4 = timeit([&] { k_salu<<<grid, 256>>>(out, 1u); });
-        float t5 = timeit([&] { k_rsq<<<grid, 256>>>(out, 0.5f); });
-        double clk = 2.4e9;
-        printf("waves/SIMD %d: fma %.3f ms (%.2f cyc/instr/SIMD @2.4GHz)  pk_fma %.3f ms (%.2f)  mix8v+8s %.3f ms (%.2f per valu)  salu-only %.3f ms (%.2f cyc/sinstr/SIMD)  rsq+add %.3f ms (%.2f cyc per pair)\n",
-               wps, t1, t1 * 1e-3 * clk / simd_instr, t2, t2 * 1e-3 * clk / simd_instr, t3, t3 * 1e-3 * clk / simd_instr,
-               t4, t4 * 1e-3 * clk / simd_instr, t5, t5 * 1e-3 * clk / ((double)ITER * 4 * waves_per_simd));
+    float *out; HC(hipMalloc(&out, 256 * 8 * 256 * sizeof(float)));
+    // ring: random permutation cycle over nrec records of 8 ints
+    for (int logn = 14; logn <= 22; logn += 4) {
+        int nrec = 1 << logn; int *h = (int *)malloc((size_t)nrec * 32); unsigned r = 12345;
+        int *perm = (int *)malloc(nrec * 4); for (int i = 0; i < nrec; i++) perm[i] = i;
+        for (int i = nrec - 1; i > 0; i--) { r = r * 1664525u + 1013904223u; int j = r % (i + 1); int t = perm[i]; perm[i] = perm[j]; perm[j] = t; }
+        for (int i = 0; i < nrec; i++) h[(size_t)perm[i] * 8] = perm[(i + 1) % nrec];
+        int *ring; HC(hipMalloc(&ring, (size_t)nrec * 32)); HC(hipMemcpy(ring, h, (size_t)nrec * 32, hipMemcpyHostToDevice));
+        for (int wps = 2; wps <= 8; wps *= 2) {
+            float t = timeit([&] { k_chase<<<256 * wps, 256>>>(out, ring, 1.0001f, 0.5f, nrec - 1); });
+            printf("chase ring %5.1f MB  waves/SIMD %d: %.3f ms  %.1f cyc/iter/SIMD (%.0f cyc/iter/wave) @2.4GHz\n", nrec * 32 / 1048576.0, wps, t,
+                   t * 1e-3 * 2.4e9 / ((double)ITER * wps), t * 1e-3 * 2.4e9 / ITER);
+        }
+        (void)hipFree(ring); free(h); free(perm);
+    }
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int grid = 256 * wps; double it = (double)ITER * wps;
+        float t1 = timeit([&] { k_v16<<<grid, 256>>>(out, 1.0001f, 0.5f); });
+        float t2 = timeit([&] { k_v16s12<<<grid, 256>>>(out, 1.0001f, 0.5f); });
+        float t3 = timeit([&] { k_s12<<<grid, 256>>>(out, 1.0001f, 0.5f); });
+        float t4 = timeit([&] { k_pk8<<<grid, 256>>>(out, 1.0001f, 0.5f); });
+        printf("waves/SIMD %d: cycles/iter/SIMD @2.4GHz: 16 VALU %.1f | 16 VALU + 12 SALU %.1f | 12 SALU %.1f | 8 pk_fma %.1f\n", wps,
+               t1 * 1e-3 * 2.4e9 / it, t2 * 1e-3 * 2.4e9 / it, t3 * 1e-3 * 2.4e9 / it, t4 * 1e-3 * 2.4e9 / it);
     }
     return 0;
 }
