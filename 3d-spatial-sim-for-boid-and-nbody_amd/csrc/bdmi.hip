@@ -68,16 +68,29 @@ __global__ __launch_bounds__(kBlock) void k_reorder(Boids a, Boids b, const uint
 
 // build_cell_lists (flock.py:47-65) from sorted keys: start (-1 if empty) and end per cell
 __global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
-                                                  int32_t *__restrict__ cell_start, int32_t *__restrict__ cell_end,
-                                                  unsigned long long *occupied) {
+                                                  int32_t *__restrict__ cell_start, int32_t *__restrict__ cell_end) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const uint32_t c = keys_s[r];
-    if (r == 0 || keys_s[r - 1] != c) {
-        cell_start[c] = (int32_t)r;
-        atomicAdd(occupied, 1ull);
-    }
+    if (r == 0 || keys_s[r - 1] != c) cell_start[c] = (int32_t)r;
     if (r == n - 1 || keys_s[r + 1] != c) cell_end[c] = (int32_t)(r + 1);
+}
+
+// number of non-empty cells of the last grid; on demand only (bdmi_grid_info), one atomic per block
+__global__ __launch_bounds__(kBlock) void k_count_cells(const uint32_t *__restrict__ keys_s, int64_t n,
+                                                        unsigned long long *occupied) {
+    __shared__ unsigned red[kBlock / 64];
+    unsigned cnt = 0;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock)
+        cnt += (r == 0 || keys_s[r - 1] != keys_s[r]) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) cnt += red[w];
+        atomicAdd(occupied, (unsigned long long)cnt);
+    }
 }
 
 // steer(): mean -> normalise * max_speed - v -> clamp to max_force -> * weight
@@ -300,8 +313,7 @@ int enqueue_grid(bdmi_flock *f, bool timed) {
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[1], st));
     k_reorder<<<nblocks(n), kBlock, 0, st>>>(f->A, f->B, f->perm, n);
     NBMI_HIP_CHECK(hipMemsetAsync(f->cell_start, 0xff, (size_t)f->num_cells * sizeof(int32_t), st));
-    NBMI_HIP_CHECK(hipMemsetAsync(f->occupied, 0, sizeof(unsigned long long), st));
-    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->cell_start, f->cell_end, f->occupied);
+    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->cell_start, f->cell_end);
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[2], st));
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
@@ -504,6 +516,13 @@ int bdmi_grid_info(bdmi_flock *f, int32_t *grid_dim, int64_t *num_cells, int64_t
     if (num_cells) *num_cells = f->num_cells;
     if (occupied) {
         unsigned long long h = 0;
+        if (f->n > 0) {
+            NBMI_HIP_CHECK(hipMemsetAsync(f->occupied, 0, sizeof(unsigned long long), f->stream));
+            int gb = nblocks(f->n);
+            if (gb > 64) gb = 64;
+            k_count_cells<<<gb, kBlock, 0, f->stream>>>(f->keys_s, f->n, f->occupied);
+            NBMI_HIP_CHECK(hipGetLastError());
+        }
         NBMI_HIP_CHECK(hipMemcpyAsync(&h, f->occupied, sizeof(h), hipMemcpyDeviceToHost, f->stream));
         NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
         *occupied = (int64_t)h;

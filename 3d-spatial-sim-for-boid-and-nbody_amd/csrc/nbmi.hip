@@ -240,84 +240,124 @@ __global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ h
 }
 
 // ---------------------------------------------------------------------------------------
-// K8: emit nodes in DFS pre-order.  Body r writes its internal cells (levels dp+1..d) at
-// r + Pex[r] + k and its leaf at r + Pex[r] + cnt.  The end of a cell is found by galloping +
-// binary search on the sorted keys.
+// K8: emit nodes in DFS pre-order.  Pre-order index of a node "started" by sorted body r:
+// internal cell k of r (levels dp+1+k, k < cnt[r]) -> r + Pex[r] + k, leaf of r -> r + Pex[r+1].
+//   k_emit_leaves  one thread per body: writes the leaf, lists the body's internal cells
+//                  (cell q = Pex[r] + k  ->  cell_r[q] = r, cell_lev[q]), sentinel, max depth.
+//   k_emit_cells   one thread per internal cell q (Karras-style, uniform work per thread): finds
+//                  the cell's last body by galloping + binary search on the sorted keys, takes
+//                  mass / COM from the float64 prefix sums and writes node r + q.
+// (A thread-per-body loop over its cells made every wave as slow as its unluckiest lane.)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_emit(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
-                                                 const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
-                                                 const Moment *__restrict__ S, const float4 *__restrict__ posm_s,
-                                                 int64_t n, double G, double inv_theta2, int64_t capacity,
-                                                 Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
-                                                 TreeInfo *info) {
+__global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
+                                                        const float4 *__restrict__ posm_s, int64_t n, int64_t capacity,
+                                                        Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
+                                                        int32_t *__restrict__ cell_r, uint8_t *__restrict__ cell_lev,
+                                                        TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    const double bounds = info->bounds;
-    const int d = delta[r];
-    const int dp = r > 0 ? delta[r - 1] : -1;
-    const int cnt = d > dp ? d - dp : 0;
-    const int64_t base = r + (int64_t)Pex[r];
-    const int64_t total = n + (int64_t)Pex[n];
-    if (r == 0) info->num_nodes = total;
-    if (total + 1 > capacity) {  // + 1: the sentinel
-        info->error = 1;
-        return;
+    if (r < n) {
+        const int64_t total = n + (int64_t)Pex[n];
+        if (r == 0) info->num_nodes = total;
+        if (total + 1 > capacity) {  // + 1: the sentinel
+            if (r == 0) info->error = 1;
+        } else {
+            const int d = delta[r];
+            const int dp = r > 0 ? delta[r - 1] : -1;
+            const int cnt = d > dp ? d - dp : 0;
+            const int64_t q0 = Pex[r];
+            for (int k = 0; k < cnt; k++) {
+                cell_r[q0 + k] = (int32_t)r;
+                cell_lev[q0 + k] = (uint8_t)(dp + 1 + k);
+            }
+            const int64_t idx = r + q0 + cnt;
+            const float4 p = posm_s[r];
+            const int leaf_level = (d > dp ? d : dp) + 1;
+            Node lf;
+            lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
+            lf.s2t = 0.0f;
+            lf.next_off = lf.seq_off = (unsigned)((idx + 1) << 5);
+            lf.ref = (int)r;
+            nodes[idx] = lf;
+            node_level[idx] = (uint8_t)leaf_level;
+            if (r == 0) {
+                Node sn;
+                sn.cx = sn.cy = sn.cz = 1.0e30f;
+                sn.gm = 0.f; sn.s2t = 0.f;
+                sn.next_off = sn.seq_off = (unsigned)(total << 5);
+                sn.ref = -1;
+                nodes[total] = sn;
+            }
+        }
     }
-    if (r == 0) {
-        Node sn;
-        sn.cx = sn.cy = sn.cz = 1.0e30f;
-        sn.gm = 0.f; sn.s2t = 0.f;
-        sn.next_off = sn.seq_off = (unsigned)(total << 5);
-        sn.ref = -1;
-        nodes[total] = sn;
+}
+
+// deepest leaf level = max(delta) + 1; only run when nbmi_tree_stats() asks (same-address
+// atomics cost ~11 ns each: one per block here, never in the per-step path)
+__global__ __launch_bounds__(kBlock) void k_max_level(const int32_t *__restrict__ delta, int64_t n, TreeInfo *info) {
+    __shared__ int red[kBlock / 64];
+    int m = -1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int d = delta[i];
+        m = d > m ? d : m;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int other = __shfl_xor(m, o);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; w++) m = red[w] > m ? red[w] : m;
+        atomicMax(&info->max_level, m + 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
+                                                       const int32_t *__restrict__ Pex, const Moment *__restrict__ S,
+                                                       const int32_t *__restrict__ cell_r, const uint8_t *__restrict__ cell_lev,
+                                                       int64_t n, double G, double inv_theta2, int64_t capacity,
+                                                       Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
+                                                       const TreeInfo *__restrict__ info) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t ncells = Pex[n];
+    if (q >= ncells || n + ncells + 1 > capacity) return;
+    const int64_t r = cell_r[q];
+    const int lev = cell_lev[q];
     const uint64_t h = hi_s[r], l = lo_s[r];
-    const Moment s0 = S[r];
-    for (int k = 0; k < cnt; k++) {
-        const int lev = dp + 1 + k;
-        // largest j with cpl(r, j) >= lev  (j = r qualifies); e = j + 1
-        int64_t ok = r, bad;
-        int64_t step = 1;
-        for (;;) {
-            const int64_t t = r + step;
-            if (t >= n) { bad = n; break; }
-            if (cpl_digits(h, l, hi_s[t], lo_s[t]) >= lev) { ok = t; step <<= 1; }
-            else { bad = t; break; }
-        }
-        while (bad - ok > 1) {
-            const int64_t mid = ok + ((bad - ok) >> 1);
-            if (cpl_digits(h, l, hi_s[mid], lo_s[mid]) >= lev) ok = mid; else bad = mid;
-        }
-        const int64_t e = bad;
-        const Moment s1 = S[e];
-        const double M = s1.m - s0.m;
-        double cx = 0.0, cy = 0.0, cz = 0.0;
-        if (M > 0.0) {
-            cx = (s1.x - s0.x) / M;
-            cy = (s1.y - s0.y) / M;
-            cz = (s1.z - s0.z) / M;
-        }
-        const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
-        Node nd;
-        nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
-        nd.gm = (float)(G * M);
-        nd.s2t = (float)(size * size * inv_theta2);
-        nd.next_off = (unsigned)((e + (int64_t)Pex[e]) << 5);
-        nd.seq_off = (unsigned)((base + k + 1) << 5);
-        nd.ref = ~(int)r;
-        nodes[base + k] = nd;
-        node_level[base + k] = (uint8_t)lev;
+    // largest j with cpl(r, j) >= lev (j = r qualifies); e = j + 1
+    int64_t ok = r, bad;
+    int64_t step = 1;
+    for (;;) {
+        const int64_t t = r + step;
+        if (t >= n) { bad = n; break; }
+        if (cpl_digits(h, l, hi_s[t], lo_s[t]) >= lev) { ok = t; step <<= 1; }
+        else { bad = t; break; }
     }
-    const float4 p = posm_s[r];
-    const int leaf_level = (d > dp ? d : dp) + 1;
-    Node lf;
-    lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
-    lf.s2t = 0.0f;
-    lf.next_off = lf.seq_off = (unsigned)((base + cnt + 1) << 5);
-    lf.ref = (int)r;
-    nodes[base + cnt] = lf;
-    node_level[base + cnt] = (uint8_t)leaf_level;
-    atomicMax(&info->max_level, leaf_level);
+    while (bad - ok > 1) {
+        const int64_t mid = ok + ((bad - ok) >> 1);
+        if (cpl_digits(h, l, hi_s[mid], lo_s[mid]) >= lev) ok = mid; else bad = mid;
+    }
+    const int64_t e = bad;
+    const Moment s0 = S[r], s1 = S[e];
+    const double M = s1.m - s0.m;
+    double cx = 0.0, cy = 0.0, cz = 0.0;
+    if (M > 0.0) {
+        cx = (s1.x - s0.x) / M;
+        cy = (s1.y - s0.y) / M;
+        cz = (s1.z - s0.z) / M;
+    }
+    const double size = ldexp(info->bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
+    const int64_t idx = r + q;
+    Node nd;
+    nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
+    nd.gm = (float)(G * M);
+    nd.s2t = (float)(size * size * inv_theta2);
+    nd.next_off = (unsigned)((e + (int64_t)Pex[e]) << 5);
+    nd.seq_off = (unsigned)((idx + 1) << 5);
+    nd.ref = ~(int)r;
+    nodes[idx] = nd;
+    node_level[idx] = (uint8_t)lev;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -704,6 +744,8 @@ struct nbmi_sim {
     Moment *W = nullptr, *S = nullptr;
     Node *nodes = nullptr;
     uint8_t *node_level = nullptr;
+    int32_t *cell_r = nullptr;  // internal-cell list: first body and level
+    uint8_t *cell_lev = nullptr;
     int64_t node_capacity = 0;
     TreeInfo *info = nullptr;  // device
     void *tmp_sort = nullptr, *tmp_scan_i = nullptr, *tmp_scan_m = nullptr;
@@ -761,7 +803,7 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     // reset maxabs/num_nodes/max_level/error (keep counters)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     int gb = nblocks(n);
-    if (gb > 2048) gb = 2048;
+    if (gb > 256) gb = 256;  // one same-address atomic per block: keep them few
     k_maxabs<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info);
     k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
@@ -775,8 +817,12 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     NBMI_HIP_CHECK(nbmi::exclusive_scan_moment(s->tmp_scan_m, s->tmp_scan_m_bytes, s->W, s->S, (size_t)n + 1, st));
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
-    k_emit<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->delta, s->Pex, s->S, s->posm_s, n, s->G, inv_theta2,
-                                          s->node_capacity, s->nodes, s->node_level, s->info);
+    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->posm_s, n, s->node_capacity, s->nodes,
+                                                 s->node_level, s->cell_r, s->cell_lev, s->info);
+    // one thread per internal cell; the count lives on the device, so launch for the row budget
+    k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->Pex, s->S, s->cell_r, s->cell_lev,
+                                                                  n, s->G, inv_theta2, s->node_capacity, s->nodes,
+                                                                  s->node_level, s->info);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], st));
     NBMI_HIP_CHECK(hipGetLastError());
     s->tree_valid = true;
@@ -896,7 +942,8 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
             dev_alloc(s, &s->W, n + 1) || dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->nodes, s->node_capacity) ||
-            dev_alloc(s, &s->node_level, s->node_capacity))
+            dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
+            dev_alloc(s, &s->cell_lev, s->node_capacity - n))
             return -2;
         s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
         s->tmp_scan_i_bytes = nbmi::scan_i32_temp_bytes((size_t)n + 1);
@@ -1110,6 +1157,12 @@ int nbmi_tree_stats(nbmi_sim *s, int64_t *num_nodes, int32_t *max_depth, double 
         if (max_depth) *max_depth = 0;
         if (bounds) *bounds = 10.0;
         return 0;
+    }
+    if (max_depth) {
+        int gb = nblocks(s->n);
+        if (gb > 64) gb = 64;
+        k_max_level<<<gb, kBlock, 0, s->stream>>>(s->delta, s->n, s->info);
+        NBMI_HIP_CHECK(hipGetLastError());
     }
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));

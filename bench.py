@@ -40,6 +40,7 @@ WORKLOADS = {
     "collision_10m_bh": ("collision", 10_000_000, 2000.0, 0.08, 6.0, 0.5, 0.25, "barnes_hut"),
     "galaxy_10k_bh": ("galaxy", 10_000, 500.0, 0.15, 3.0, 0.5, 0.2, "barnes_hut"),
     "cluster_1m_direct": ("cluster_fast", 1_000_000, 300.0, 0.05, 1.0, 0.0, 0.02, "direct"),
+    "boids_2m": ("boids", 2_000_000, 500.0, 0.0, 0.0, 0.0, 1.0 / 60.0, "boids"),
 }
 
 
@@ -97,6 +98,65 @@ def cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=25.0):
                       f"(serial build {ph[2]:.2f}s + {cores}-thread walk {ph[3]:.2f}s per step; -O3 -ffast-math)"}
 
 
+def bench_boids(args, n, dt):
+    """BASELINE config 5: boids/flock.py, 2 M boids, reference constants, dt = 1/60 (one GPU)."""
+    import torch
+    from boids import Flock
+    from oracle import pyref
+    fl = Flock(n, seed=42)
+    p0, v0, c0 = fl.positions.copy(), fl.velocities.copy(), fl.colors.copy()
+
+    def fence():
+        fl.sync()
+        torch.cuda.synchronize()
+
+    fl.update(dt, args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    fl.update(dt, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    fl.enable_timers(True)
+    fl.timers(reset=True)
+    fl.update(dt, args.steps)
+    fence()
+    tm = fl.timers(reset=True)
+    k = max(1, tm["steps"])
+    sweep_ms = tm["sweep_ms"] / k
+    info = fl.grid_info()
+    # algorithmic bytes of the sweep kernel per boid: own state 72 r + 76 w, 27 cell-table entries
+    # (start,end) 216, candidates (~occupancy-dependent, measured below) x 24 (+48 when in range)
+    cand = 27.0 * n / info["num_cells"]
+    alg = n * (72 + 76 + 216 + cand * 24.0 + 1.0 * 48.0)
+    ach = alg / (sweep_ms * 1e-3) / 1e9
+    out = {"metric": "boid-steps/sec (boids sep/align/cohesion sweep)", "value": n * args.steps / elapsed,
+           "unit": "boid-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic (reference Flock ICs, seed 42)",
+           "config": {"workload": "boids_2m", "boids": n, "bounds": 500.0, "perception_radius": 5.0, "dt": dt,
+                      "grid_dim": info["grid_dim"], "num_cells": info["num_cells"]},
+           "phase_ms": {key: tm[key] / k for key in ("sort_ms", "table_ms", "sweep_ms")},
+           "roofline": {"bound": "hbm", "kernel": "k_flock", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg,
+                        "kernel_ms": sweep_ms, "occupied_cells": info["occupied"]}}
+    if not args.no_cpu_baseline:
+        try:
+            L = pyref.lib(path=pyref.build(fast=True, native=True, out_dir="/tmp"))
+        except Exception:
+            L = pyref.lib(fast=True)
+        st = pyref.FlockStepper(p0, v0, c0, pyref.boids_params(), use_numpy_argsort=True, L=L)
+        st.step(dt)
+        t0 = time.perf_counter()
+        ksteps = 5
+        for _ in range(ksteps):
+            st.step(dt)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n * ksteps / t, "unit": "boid-steps/s", "cores": int(L.nbref_num_threads()),
+                               "kind": "port", "sample": f"{ksteps} full Flock.update steps of the same {n}-boid "
+                               "workload after 1 warm-up (np.argsort + serial cell lists + OpenMP sweep)"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +182,9 @@ def main():
     dist_name, per_gpu, R, G, eps, theta, dt, method = WORKLOADS[args.workload]
     if args.bodies_per_gpu:
         per_gpu = args.bodies_per_gpu
+    if method == "boids":
+        assert world == 1, "boids run as replicas only (DESIGN.md section 6)"
+        return bench_boids(args, per_gpu, dt)
     n_total = per_gpu * world
     p, v, m = make_ic(dist_name, n_total, R, G)
 
