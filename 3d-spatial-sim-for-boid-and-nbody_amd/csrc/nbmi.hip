@@ -82,6 +82,7 @@ struct TreeInfo {
     unsigned long long wave_visits, lane_visits, lane_accepts;
     unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
     unsigned long long jumps;        // cursor moves other than c -> c+1
+    unsigned long long xcd_visits[8];  // counted walk: wave-level visits executed on each XCD
 };
 
 // ---------------------------------------------------------------------------------------
@@ -497,6 +498,8 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         if (kCount) {
             // wave_visits counted once per wave (lane 0), lane counters summed over lanes
             if (lane == 0) {
+                const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 7u;
+                atomicAdd(&info_out->xcd_visits[xcc], wv);
                 atomicAdd(&info_out->wave_visits, wv);
                 for (int w = 0; w < 4; w++) atomicAdd(&info_out->win_miss[w], wm[w]);
                 atomicAdd(&info_out->jumps, jm);
@@ -1138,7 +1141,7 @@ int nbmi_get_accelerations_f64(nbmi_sim *s, double *out) {
     double *acc = (double *)s->stage;
     if (s->method == NBMI_METHOD_BARNES_HUT) {
         if (int rc = enqueue_tree(s, -1)) return rc;
-        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 8 * sizeof(unsigned long long), s->stream));
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 16 * sizeof(unsigned long long), s->stream));
         if (int rc = enqueue_walk(s, false, 0.0, acc)) return rc;
     } else {
         if (int rc = launch_direct<false>(s, 0.0, acc)) return rc;
@@ -1241,7 +1244,7 @@ int nbmi_get_timers(nbmi_sim *s, double *ms5, int64_t *count, int reset) {
     return 0;
 }
 
-int nbmi_walk_counters(nbmi_sim *s, int64_t *out8) {
+int nbmi_walk_counters(nbmi_sim *s, int64_t *out8 /* 16 entries */) {
     if (int rc = check_handle(s)) return rc;
     int64_t *out3 = out8;
     if (!out3) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
@@ -1251,6 +1254,7 @@ int nbmi_walk_counters(nbmi_sim *s, int64_t *out8) {
     out3[0] = (int64_t)h.wave_visits; out3[1] = (int64_t)h.lane_visits; out3[2] = (int64_t)h.lane_accepts;
     for (int w = 0; w < 4; w++) out8[3 + w] = (int64_t)h.win_miss[w];
     out8[7] = (int64_t)h.jumps;
+    for (int x = 0; x < 8; x++) out8[8 + x] = (int64_t)h.xcd_visits[x];
     return 0;
 }
 

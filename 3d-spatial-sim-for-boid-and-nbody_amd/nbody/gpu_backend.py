@@ -211,10 +211,11 @@ class HIPBarnesHutSimulation(_HIPSimulation):
         return level, key
 
     def walk_counters(self):
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(16, dtype=np.int64)
         _nat.check(self._lib.nbmi_walk_counters(self._h, _nat.ptr(out)), "nbmi_walk_counters")
         return dict(wave_visits=int(out[0]), lane_visits=int(out[1]), lane_accepts=int(out[2]),
-                    window_misses={8 << w: int(out[3 + w]) for w in range(4)}, jumps=int(out[7]))
+                    window_misses={8 << w: int(out[3 + w]) for w in range(4)}, jumps=int(out[7]),
+                    xcd_visits=[int(v) for v in out[8:16]])
 
     # multi-GPU hooks (device pointers; see nbody/sharded.py)
     def set_shard(self, begin, end):

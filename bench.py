@@ -261,7 +261,8 @@ def main():
                                "num_nodes": ts["num_nodes"], "max_depth": ts["max_depth"],
                                "window_misses_per_group": {str(k): v / max(1, (n_total + 63) // 64)
                                                            for k, v in wc["window_misses"].items()},
-                               "jumps_per_group": wc["jumps"] / max(1, (n_total + 63) // 64)}
+                               "jumps_per_group": wc["jumps"] / max(1, (n_total + 63) // 64),
+                               "xcd_visit_share": [round(v / max(1, wc["wave_visits"]), 4) for v in wc["xcd_visits"]]}
         else:
             flops = 20.0 * n_total * n_total
             ach = flops / (walk_ms * 1e-3) / 1e12

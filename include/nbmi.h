@@ -99,8 +99,8 @@ int nbmi_enable_timers(nbmi_sim *sim, int enable);
 int nbmi_get_timers(nbmi_sim *sim, double *ms5, int64_t *count, int reset);
 /* Work counters of the last counted walk (nbmi_get_accelerations_f64): [wave-level node visits,
  * lane-level visits, lane accepts, node-window misses for windows of 8/16/32/64 nodes,
- * non-sequential cursor moves]. */
-int nbmi_walk_counters(nbmi_sim *sim, int64_t *out8);
+ * non-sequential cursor moves, wave-level visits executed on each of the 8 XCDs] (16 values). */
+int nbmi_walk_counters(nbmi_sim *sim, int64_t *out16);
 
 /* Multi-GPU (one process per GPU).  A handle created with nbmi_create holds ALL bodies; with a
  * shard set, step() integrates only the key-sorted ranks [begin,end) and leaves the others

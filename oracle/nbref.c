@@ -417,18 +417,19 @@ void nbref_group_walk_stats(const double *pos, const int64_t *order, int64_t n, 
     for (int64_t g = 0; g < ngroups; g++) {
         int64_t lo = g * gs, hi = lo + gs > n ? n : lo + gs;
         int cnt = (int)(hi - lo);
-        /* explicit stack of (node, active mask) - masks up to 64 members */
+        /* explicit stack of (node, active mask) - masks up to 128 members */
+        typedef unsigned __int128 mask_t;
         int cap = 4096, sp = 0;
         int32_t *sn = (int32_t *)malloc(sizeof(int32_t) * cap);
-        uint64_t *sm = (uint64_t *)malloc(sizeof(uint64_t) * cap);
-        sn[0] = 0; sm[0] = (cnt == 64) ? ~0ULL : ((1ULL << cnt) - 1); sp = 1;
+        mask_t *sm = (mask_t *)malloc(sizeof(mask_t) * cap);
+        sn[0] = 0; sm[0] = (cnt == 128) ? ~(mask_t)0 : ((((mask_t)1) << cnt) - 1); sp = 1;
         int64_t uni = 0;
         while (sp > 0) {
             sp--;
             int32_t node = sn[sp];
-            uint64_t mask = sm[sp];
+            mask_t mask = sm[sp];
             uni++;
-            uint64_t open = 0;
+            mask_t open = 0;
             for (int l = 0; l < cnt; l++) {
                 if (!((mask >> l) & 1)) continue;
                 sum_body++;
@@ -437,7 +438,7 @@ void nbref_group_walk_stats(const double *pos, const int64_t *order, int64_t n, 
                 double dx = com[3 * node] - pos[3 * i], dy = com[3 * node + 1] - pos[3 * i + 1],
                        dz = com[3 * node + 2] - pos[3 * i + 2];
                 double dist = sqrt(dx * dx + dy * dy + dz * dz + eps2);
-                if (!(half[node] * 2.0 / dist < theta)) open |= 1ULL << l;
+                if (!(half[node] * 2.0 / dist < theta)) open |= ((mask_t)1) << l;
             }
             if (open) {
                 for (int c = 0; c < 8; c++) {
@@ -446,7 +447,7 @@ void nbref_group_walk_stats(const double *pos, const int64_t *order, int64_t n, 
                         if (sp == cap) {
                             cap *= 2;
                             sn = (int32_t *)realloc(sn, sizeof(int32_t) * cap);
-                            sm = (uint64_t *)realloc(sm, sizeof(uint64_t) * cap);
+                            sm = (mask_t *)realloc(sm, sizeof(mask_t) * cap);
                         }
                         sn[sp] = ch; sm[sp] = open; sp++;
                     }
