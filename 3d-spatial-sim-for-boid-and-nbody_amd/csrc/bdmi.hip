@@ -6,11 +6,12 @@
 // float64 state and arithmetic like the reference (this path is bandwidth bound; MI355X
 // float64 vector rate is far above what ~7 candidates per boid need).
 //
-// HBM layout: SoA float64 {p, v, c} x 3 + int32 id, kept in CELL-SORTED order between steps
-// (buffer A).  Per step: cell keys from A -> radix sort (cell, rank) -> gather A into B in the
-// new order -> dense cell table (start, end) from the sorted keys -> sweep kernel reads
-// neighbours from B (contiguous per cell, and the three x-adjacent cells of a row are
-// contiguous too) and writes the updated boid back to A at the same rank, physics fused.
+// HBM layout: master state SoA float64 {p, v, c} x 3 + int32 id, kept in CELL-SORTED order
+// between steps (buffer A).  Per step: cell keys from A -> radix sort (cell, rank) -> gather A into
+// the read-side copy B (array of 32-byte {x,y,z,-} records per quantity: one cache line per
+// neighbour position) -> 1-bit-per-cell occupancy map + {start,end} pair per non-empty cell ->
+// sweep kernel tests the occupancy bit (L2 resident) before touching the pair table, reads
+// neighbours from B and writes the updated boid back to A at the same rank, physics fused.
 #include <stddef.h>
 #include <string.h>
 
@@ -26,6 +27,13 @@ constexpr int kBlock = 256;
 
 struct Boids {
     double *px, *py, *pz, *vx, *vy, *vz, *cr, *cg, *cb;
+    int32_t *id;
+};
+
+// read-side copy of the boids for the sweep: array of structures, one 32-byte record per boid and
+// quantity, so that a neighbour's position is ONE cache line (the SoA master touches three)
+struct BoidsAoS {
+    double4 *p, *v, *c;  // {x,y,z,-}, {vx,vy,vz,-}, {r,g,b,-}
     int32_t *id;
 };
 
@@ -56,24 +64,29 @@ __global__ __launch_bounds__(kBlock) void k_assign(Boids a, int64_t n, GridP g, 
     idx[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_reorder(Boids a, Boids b, const uint32_t *__restrict__ perm, int64_t n) {
+__global__ __launch_bounds__(kBlock) void k_reorder(Boids a, BoidsAoS b, const uint32_t *__restrict__ perm, int64_t n) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const uint32_t j = perm[r];
-    b.px[r] = a.px[j]; b.py[r] = a.py[j]; b.pz[r] = a.pz[j];
-    b.vx[r] = a.vx[j]; b.vy[r] = a.vy[j]; b.vz[r] = a.vz[j];
-    b.cr[r] = a.cr[j]; b.cg[r] = a.cg[j]; b.cb[r] = a.cb[j];
+    b.p[r] = make_double4(a.px[j], a.py[j], a.pz[j], 0.0);
+    b.v[r] = make_double4(a.vx[j], a.vy[j], a.vz[j], 0.0);
+    b.c[r] = make_double4(a.cr[j], a.cg[j], a.cb[j], 0.0);
     b.id[r] = a.id[j];
 }
 
-// build_cell_lists (flock.py:47-65) from sorted keys: start (-1 if empty) and end per cell
+// build_cell_lists (flock.py:47-65) from sorted keys.  The first boid of a cell sets the cell's bit
+// in a 1-bit-per-cell occupancy map (1 MB at the reference grid: L2 resident, cleared per step
+// instead of a 33 MB table) and writes the cell's {start, end} pair; empty cells are never read.
 __global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
-                                                  int32_t *__restrict__ cell_start, int32_t *__restrict__ cell_end) {
+                                                  uint32_t *__restrict__ occ, int2 *__restrict__ cell_range) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const uint32_t c = keys_s[r];
-    if (r == 0 || keys_s[r - 1] != c) cell_start[c] = (int32_t)r;
-    if (r == n - 1 || keys_s[r + 1] != c) cell_end[c] = (int32_t)(r + 1);
+    if (r > 0 && keys_s[r - 1] == c) return;  // not the first boid of its cell
+    int64_t e = r + 1;
+    while (e < n && keys_s[e] == c) e++;
+    cell_range[c] = make_int2((int)r, (int)e);
+    atomicOr(&occ[c >> 5], 1u << (c & 31));
 }
 
 // number of non-empty cells of the last grid; on demand only (bdmi_grid_info), one atomic per block
@@ -115,18 +128,20 @@ __device__ __forceinline__ bool steer(double &x, double &y, double &z, double vx
 // compute_flocking_spatial (flock.py:68-238) + update_physics_numba (flock.py:241-308).
 // kPhysics=false: write the four force arrays (caller's boid order) instead of integrating.
 template <bool kPhysics>
-__global__ __launch_bounds__(kBlock) void k_flock(Boids b, Boids a, const int32_t *__restrict__ cell_start,
-                                                  const int32_t *__restrict__ cell_end, int64_t n, GridP g, FlockP P,
+__global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uint32_t *__restrict__ occ,
+                                                  const int2 *__restrict__ cell_range, int64_t n, GridP g, FlockP P,
                                                   double *__restrict__ o_sep, double *__restrict__ o_ali,
                                                   double *__restrict__ o_coh, double *__restrict__ o_avg) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    const double pix = b.px[r], piy = b.py[r], piz = b.pz[r];
-    const double vix = b.vx[r], viy = b.vy[r], viz = b.vz[r];
-    const double cir = b.cr[r], cig = b.cg[r], cib = b.cb[r];
+    const double4 pi4 = b.p[r], vi4 = b.v[r], ci4 = b.c[r];
+    const double pix = pi4.x, piy = pi4.y, piz = pi4.z;
+    const double vix = vi4.x, viy = vi4.y, viz = vi4.z;
+    const double cir = ci4.x, cig = ci4.y, cib = ci4.z;
     const int cx = cell_coord(pix, g), cy = cell_coord(piy, g), cz = cell_coord(piz, g);
     double sx = 0, sy = 0, sz = 0, alx = 0, aly = 0, alz = 0, cox = 0, coy = 0, coz = 0, clr = 0, clg = 0, clb = 0;
     int sep_count = 0, nb_count = 0;
+    // same visiting order as the reference: dcx outermost, dcz innermost (flock.py:117-132)
     for (int dcx = -g.range; dcx <= g.range; dcx++) {
         const int ncx = cx + dcx;
         if (ncx < 0 || ncx >= g.dim) continue;
@@ -137,13 +152,12 @@ __global__ __launch_bounds__(kBlock) void k_flock(Boids b, Boids a, const int32_
                 const int ncz = cz + dcz;
                 if (ncz < 0 || ncz >= g.dim) continue;
                 const int64_t cell = ncx + (int64_t)ncy * g.dim + (int64_t)ncz * g.dim * g.dim;
-                const int32_t start = cell_start[cell];
-                if (start < 0) continue;
-                const int32_t end = cell_end[cell];
-                for (int32_t q = start; q < end; q++) {
+                if (!((occ[cell >> 5] >> (cell & 31)) & 1u)) continue;  // empty cell: no table read
+                const int2 range = cell_range[cell];
+                for (int32_t q = range.x; q < range.y; q++) {
                     if (q == r) continue;
-                    const double qx = b.px[q], qy = b.py[q], qz = b.pz[q];
-                    const double dx = pix - qx, dy = piy - qy, dz = piz - qz;
+                    const double4 qp = b.p[q];
+                    const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
                     const double dist_sq = dx * dx + dy * dy + dz * dz;
                     if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
                         const double dist = sqrt(dist_sq);
@@ -154,9 +168,10 @@ __global__ __launch_bounds__(kBlock) void k_flock(Boids b, Boids a, const int32_
                             sz += dz * inv_dist / dist;
                             sep_count++;
                         }
-                        alx += b.vx[q]; aly += b.vy[q]; alz += b.vz[q];
-                        cox += qx; coy += qy; coz += qz;
-                        clr += b.cr[q]; clg += b.cg[q]; clb += b.cb[q];
+                        const double4 qv = b.v[q], qc = b.c[q];
+                        alx += qv.x; aly += qv.y; alz += qv.z;
+                        cox += qp.x; coy += qp.y; coz += qp.z;
+                        clr += qc.x; clg += qc.y; clb += qc.z;
                         nb_count++;
                     }
                 }
@@ -248,9 +263,12 @@ struct bdmi_flock {
     int64_t num_cells = 0;
     int key_bits = 0;
     hipStream_t stream = nullptr;
-    Boids A = {}, B = {};
+    Boids A = {};
+    BoidsAoS B = {};
     uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *perm = nullptr;
-    int32_t *cell_start = nullptr, *cell_end = nullptr;
+    uint32_t *occ = nullptr;       // 1 bit per cell
+    int2 *cell_range = nullptr;    // {start, end} of non-empty cells
+    int64_t occ_words = 0;
     unsigned long long *occupied = nullptr;
     void *tmp_sort = nullptr;
     size_t tmp_sort_bytes = 0;
@@ -312,8 +330,8 @@ int enqueue_grid(bdmi_flock *f, bool timed) {
                                             (size_t)n, 0, f->key_bits, st));
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[1], st));
     k_reorder<<<nblocks(n), kBlock, 0, st>>>(f->A, f->B, f->perm, n);
-    NBMI_HIP_CHECK(hipMemsetAsync(f->cell_start, 0xff, (size_t)f->num_cells * sizeof(int32_t), st));
-    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->cell_start, f->cell_end);
+    NBMI_HIP_CHECK(hipMemsetAsync(f->occ, 0, (size_t)f->occ_words * sizeof(uint32_t), st));
+    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->occ, f->cell_range);
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[2], st));
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
@@ -341,10 +359,13 @@ static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, c
     NBMI_HIP_CHECK(hipSetDevice(f->device));
     NBMI_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     for (auto &e : f->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
-    if (alloc_boids(f, &f->A, n) || alloc_boids(f, &f->B, n)) return -2;
+    f->occ_words = (f->num_cells + 31) / 32;
+    if (alloc_boids(f, &f->A, n)) return -2;
+    if (dev_alloc(f, &f->B.p, n) || dev_alloc(f, &f->B.v, n) || dev_alloc(f, &f->B.c, n) || dev_alloc(f, &f->B.id, n))
+        return -2;
     if (dev_alloc(f, &f->keys, n) || dev_alloc(f, &f->keys_s, n) || dev_alloc(f, &f->idx, n) ||
-        dev_alloc(f, &f->perm, n) || dev_alloc(f, &f->cell_start, (size_t)f->num_cells) ||
-        dev_alloc(f, &f->cell_end, (size_t)f->num_cells) || dev_alloc(f, &f->occupied, 1) ||
+        dev_alloc(f, &f->perm, n) || dev_alloc(f, &f->occ, (size_t)f->occ_words) ||
+        dev_alloc(f, &f->cell_range, (size_t)f->num_cells) || dev_alloc(f, &f->occupied, 1) ||
         dev_alloc(f, &f->stage, (size_t)12 * (n ? n : 1)))
         return -2;
     f->tmp_sort_bytes = nbmi::sort_pairs32_temp_bytes((size_t)n, 0, f->key_bits);
@@ -418,7 +439,7 @@ int bdmi_step(bdmi_flock *f, double dt, int substeps) {
     const FlockP P = make_params(f, dt);
     for (int k = 0; k < substeps; k++) {
         if (int rc = enqueue_grid(f, f->timers)) return rc;
-        k_flock<true><<<nblocks(f->n), kBlock, 0, f->stream>>>(f->B, f->A, f->cell_start, f->cell_end, f->n, f->grid, P,
+        k_flock<true><<<nblocks(f->n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_range, f->n, f->grid, P,
                                                                nullptr, nullptr, nullptr, nullptr);
         NBMI_HIP_CHECK(hipGetLastError());
         if (f->timers) {
@@ -499,7 +520,7 @@ int bdmi_get_forces(bdmi_flock *f, double *sep, double *ali, double *coh, double
     if (int rc = enqueue_grid(f, false)) return rc;
     double *d0 = f->stage, *d1 = d0 + 3 * n, *d2 = d1 + 3 * n, *d3 = d2 + 3 * n;
     const FlockP P = make_params(f, 0.0);
-    k_flock<false><<<nblocks(n), kBlock, 0, f->stream>>>(f->B, f->A, f->cell_start, f->cell_end, n, f->grid, P, d0, d1,
+    k_flock<false><<<nblocks(n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_range, n, f->grid, P, d0, d1,
                                                          d2, d3);
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipMemcpyAsync(sep, d0, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));

@@ -22,18 +22,32 @@ WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 PASSES
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
-import csv, glob, os, collections
+import csv, glob, os, collections, json
 out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_'+os.environ.get('TAG','x')
+KEYS=('k_walk<true','k_walk<false','k_emit_cells','k_emit_leaves','k_gather','k_keys','k_maxabs','k_direct','k_flock<true','k_reorder','k_table','k_assign')
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
+dur=collections.defaultdict(list)
 for f in glob.glob(out+'/pass*/*/*counter_collection.csv'):
+    seen=set()
     for r in csv.DictReader(open(f)):
-        k=r['Kernel_Name'].split('(')[0][-40:]
-        agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
-with open(out+'/summary.txt','w') as fo:
-    for k,d in agg.items():
-        if 'k_walk' in k or 'k_emit' in k or 'k_direct' in k or 'k_flock' in k:
-            fo.write(k+'\n')
-            for c,v in sorted(d.items()):
-                fo.write(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
-print(open(out+'/summary.txt').read())
+        n=r['Kernel_Name']
+        k=[x for x in KEYS if x in n]
+        if not k: continue
+        agg[k[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        did=(f, r['Dispatch_Id'])
+        if did not in seen:
+            seen.add(did); dur[k[0]].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+res={}
+for k,d in agg.items():
+    res[k]={c: sum(v)/len(v) for c,v in d.items()}
+    res[k]['_dispatches']=max(len(v) for v in d.values())
+    res[k]['_avg_us_under_pmc']=sum(dur[k])/len(dur[k])
+    fs=res[k].get('FETCH_SIZE'); ws=res[k].get('WRITE_SIZE')
+    if fs is not None and ws is not None:
+        # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are KiB; gfx950 FETCH_SIZE reads 1/2 for wide coalesced reads
+        res[k]['hbm_bytes_raw']=(fs+ws)*1024
+        res[k]['hbm_bytes_fetch_x2']=(2*fs+ws)*1024
+json.dump(res, open(out+'/summary.json','w'), indent=1, sort_keys=True)
+for k,d in res.items():
+    print(k, {c: (round(v,1) if isinstance(v,float) else v) for c,v in d.items() if c in ('FETCH_SIZE','WRITE_SIZE','hbm_bytes_raw','hbm_bytes_fetch_x2','_avg_us_under_pmc','TCC_HIT_sum','TCC_MISS_sum','SQ_INSTS_VALU','SQ_INSTS_SALU','SQ_WAVES')})
 PY
