@@ -44,6 +44,20 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload, kernel_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/, collected with scripts/gpu_pmc.sh): (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    i.e. with the gfx950 read-side correction MI355X_MICROARCH.md prescribes.  None if absent."""
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)[kernel_key]
+        return {"bytes": d["hbm_bytes_fetch_x2"], "bytes_uncorrected": d["hbm_bytes_raw"],
+                "source": os.path.relpath(path, ROOT)}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_ic(dist_name, n, R, G):
     from tools.presets import generate_distribution
     np.random.seed(42)
@@ -139,7 +153,9 @@ def bench_boids(args, n, dt):
                       "grid_dim": info["grid_dim"], "num_cells": info["num_cells"]},
            "phase_ms": {key: tm[key] / k for key in ("sort_ms", "table_ms", "sweep_ms")},
            "roofline": {"bound": "hbm", "kernel": "k_flock", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "alg_bytes_per_launch": alg,
+                        "frac": ach / HBM_PEAK_GBS,
+                        "traffic": (pmc_traffic("boids_2m", "k_flock<true") or {}).get("bytes") if n == 2_000_000 else None,
+                        "alg_bytes_per_launch": alg,
                         "kernel_ms": sweep_ms, "occupied_cells": info["occupied"]}}
     if not args.no_cpu_baseline:
         try:
@@ -254,8 +270,10 @@ def main():
             ts = sim.tree_stats()
             alg_bytes = wc["wave_visits"] * NODE_BYTES + n_total * BODY_BYTES_WALK
             ach = alg_bytes / (walk_ms * 1e-3) / 1e9
+            tr = pmc_traffic(args.workload, "k_walk<true") if not args.bodies_per_gpu else None
             out["roofline"] = {"bound": "hbm", "kernel": "k_walk", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr["bytes"] if tr else None,
+                               "traffic_detail": tr,
                                "alg_bytes_per_launch": alg_bytes, "kernel_ms": walk_ms,
                                "wave_visits_per_group": wc["wave_visits"] / max(1, (n_total + 63) // 64),
                                "lane_visits_per_body": wc["lane_visits"] / n_total,
