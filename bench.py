@@ -18,6 +18,7 @@ Rank 0 prints ONE JSON line.  At N = 1 it also carries
                  Numba fastmath) timed on this host for a bounded sample of the same workload.
 """
 import argparse
+import contextlib
 import importlib
 import json
 import os
@@ -117,7 +118,8 @@ def bench_boids(args, n, dt):
     import torch
     from boids import Flock
     from oracle import pyref
-    fl = Flock(n, seed=42)
+    with contextlib.redirect_stdout(sys.stderr):
+        fl = Flock(n, seed=42)
     p0, v0, c0 = fl.positions.copy(), fl.velocities.copy(), fl.colors.copy()
 
     def fence():
@@ -207,16 +209,17 @@ def main():
     p, v, m = make_ic(dist_name, n_total, R, G)
 
     from nbody import gpu_backend as gb
-    if world > 1:
-        from nbody.sharded import create_sharded_simulation
-        assert method == "barnes_hut"
-        sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta)
-        sim = sharded.engine.sim
-        step = lambda k: sharded.step(dt, k)  # noqa: E731
-    else:
-        sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=local) if method == "barnes_hut"
-               else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=local))
-        step = lambda k: sim.step_many(dt, k)  # noqa: E731
+    with contextlib.redirect_stdout(sys.stderr):  # backend banners must not pollute the one JSON line
+        if world > 1:
+            from nbody.sharded import create_sharded_simulation
+            assert method == "barnes_hut"
+            sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta)
+            sim = sharded.engine.sim
+            step = lambda k: sharded.step(dt, k)  # noqa: E731
+        else:
+            sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=local) if method == "barnes_hut"
+                   else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=local))
+            step = lambda k: sim.step_many(dt, k)  # noqa: E731
 
     def fence():
         sim.sync()

@@ -167,7 +167,8 @@ int64_t nbref_build_octree(const double *pos, const double *masses, int64_t n, d
 }
 
 /* stats[0]=total visits, [1]=accepted-with-force, [2]=dropped pushes (stack full),
- * [3]=peak stack occupancy, [4]=opened nodes. May be NULL. */
+ * [3]=peak stack occupancy, [4]=opened nodes, [5]=visits of single-child internal nodes
+ * ("chain" cells; design analysis). May be NULL (6 entries otherwise). */
 void nbref_compute_forces_bh(const double *pos, const double *masses, double *acc,
                              const double *centers, const double *half, const double *nmass,
                              const double *com, const int32_t *children, const int32_t *body_idx,
@@ -175,9 +176,9 @@ void nbref_compute_forces_bh(const double *pos, const double *masses, double *ac
                              double G, double softening, int64_t *stats) {
     (void)masses; (void)centers;
     const double eps2 = softening * softening;
-    int64_t visits = 0, accepted = 0, dropped = 0, opened = 0;
+    int64_t visits = 0, accepted = 0, dropped = 0, opened = 0, chain = 0;
     int peak = 0;
-#pragma omp parallel for schedule(dynamic, 256) reduction(+ : visits, accepted, dropped, opened) reduction(max : peak)
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : visits, accepted, dropped, opened, chain) reduction(max : peak)
     for (int64_t i = 0; i < n; i++) {
         double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
         double ax = 0.0, ay = 0.0, az = 0.0;
@@ -189,6 +190,11 @@ void nbref_compute_forces_bh(const double *pos, const double *masses, double *ac
             int64_t node = stack[sp];
             if (node < 0 || node >= num_nodes) continue;
             visits++;
+            if (!is_leaf[node]) {
+                int nch = 0;
+                for (int c = 0; c < 8; c++) nch += children[8 * node + c] >= 0;
+                chain += nch == 1;
+            }
             if (is_leaf[node] && body_idx[node] == i) continue;
             double dx = com[3 * node] - px;
             double dy = com[3 * node + 1] - py;
@@ -223,7 +229,7 @@ void nbref_compute_forces_bh(const double *pos, const double *masses, double *ac
         acc[3 * i] = ax; acc[3 * i + 1] = ay; acc[3 * i + 2] = az;
     }
     if (stats) {
-        stats[0] = visits; stats[1] = accepted; stats[2] = dropped; stats[3] = peak; stats[4] = opened;
+        stats[0] = visits; stats[1] = accepted; stats[2] = dropped; stats[3] = peak; stats[4] = opened; stats[5] = chain;
     }
 }
 

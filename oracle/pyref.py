@@ -140,12 +140,12 @@ def build_octree(pos, masses, bounds, nd, cap=MAX_TREE_NODES, L=None):
 def compute_forces_barnes_hut(pos, masses, nd, num_nodes, theta, G, softening, stats=False, L=None):
     L = L or lib()
     acc = np.zeros((len(pos), 3))
-    st = np.zeros(5, dtype=np.int64)
+    st = np.zeros(6, dtype=np.int64)
     L.nbref_compute_forces_bh(pos, masses, acc, nd.centers, nd.half, nd.mass, nd.com, nd.children, nd.body,
                               nd.leaf, num_nodes, len(pos), theta, G, softening, st.ctypes.data)
     if stats:
         return acc, dict(visits=int(st[0]), accepted=int(st[1]), dropped=int(st[2]), peak_stack=int(st[3]),
-                         opened=int(st[4]))
+                         opened=int(st[4]), chain_visits=int(st[5]))
     return acc
 
 
@@ -199,7 +199,7 @@ class BHStepper:
         self.cap = cap
         self.nd = NodeArrays.for_bodies(self.n, rows)
         self.num_nodes = 0
-        self.stats = np.zeros(5, dtype=np.int64)
+        self.stats = np.zeros(6, dtype=np.int64)
         self.phase_s = np.zeros(5)
 
     def step(self, dt):

@@ -368,7 +368,7 @@ def test_collision_10m_tree_vs_uncapped_oracle(gpu, oracle):
     m2 = np.ascontiguousarray(m[order])
     body2 = np.where(nd.body[:nn] >= 0, inv[np.clip(nd.body[:nn], 0, n - 1)], -1).astype(np.int32)
     acc2 = np.zeros((n, 3))
-    stats = np.zeros(5, dtype=np.int64)
+    stats = np.zeros(6, dtype=np.int64)
     L.nbref_compute_forces_bh(p2, m2, acc2, nd.centers, nd.half, nd.mass, nd.com, nd.children, body2, nd.leaf, nn,
                               len(sample), 0.5, 0.08, 6.0, stats.ctypes.data)
     err = _rel_err(acc[sample], acc2[:len(sample)])
