@@ -81,7 +81,7 @@ struct TreeInfo {
     int error;                       // 1 = node capacity exceeded
     unsigned long long wave_visits, lane_visits, lane_accepts;
     unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
-    unsigned long long jumps;        // cursor moves other than c -> c+1
+    unsigned long long jumps;        // cursor moves other than to the next node in memory
     unsigned long long xcd_visits[8];  // counted walk: wave-level visits executed on each XCD
 };
 
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor `c` over the
+// K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor over the
 // pre-order node array (one scalar s_load_dwordx8 per visit); per lane the reference's test
 // (simulation.py:245-274):
 //     d = com - p; dist_sq = |d|^2 + eps^2;
@@ -371,12 +371,11 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 // The reference's explicit "skip my own leaf" needs no instruction here: the own leaf has d = 0
 // exactly, so its term is 0 (eps > 0) or fails the dist_sq > eps^2 guard (kGuard, eps == 0).
 // `resume` = first node index at which the lane takes part again (it accepted an ancestor of
-// everything before that).  The cursor moves to c+1 if any lane opens the node, else to
-// node.next.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
+// everything before that).  The cursor moves to seq_off if any lane opens the node, else to
+// next_off.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
 // written at the body's NEW sorted rank (state re-ordering is fused into this kernel).
 // ---------------------------------------------------------------------------------------
 struct WalkParams {
-    int64_t n;
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
     float eps2;
     int xcd_chunk;  // see logical_block()
@@ -757,7 +756,6 @@ struct nbmi_sim {
     void *stage = nullptr;    // getter staging, 3N doubles
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
-    bool count_walk = false;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     // timers
     bool timers = false;
@@ -837,7 +835,6 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf], nxt = s->buf[1 - s->curbuf];
     WalkParams P;
-    P.n = n;
     P.rank_begin = integrate ? s->shard_begin : 0;
     P.rank_end = integrate ? s->shard_end : n;
     P.eps2 = (float)(s->softening * s->softening);
