@@ -380,3 +380,52 @@ def test_collision_10m_tree_vs_uncapped_oracle(gpu, oracle):
     x = sim.get_positions_f64()
     assert np.isfinite(x).all() and np.abs(x - (p + 0.25 * sim.get_velocities())).max() < 1e-9
     sim.close()
+
+
+def test_random_trees_vs_oracle_stress(gpu, oracle):
+    """60 random inputs (sizes 2..6000; uniform, clustered, anisotropic; tight pairs down to 1e-9 of the
+    box so that octant paths exceed 21 levels and the second key word / tie-fix path is used):
+    bounds, node count, depth, level histogram, <=21-level cell set and keys must equal the oracle's;
+    accelerations within the fp32 bound."""
+    rng = np.random.RandomState(2024)
+    worst = 0.0
+    for case in range(60):
+        n = int(rng.choice([2, 3, 17, 64, 65, 127, 500, 1000, 2049, 6000]))
+        kind = case % 4
+        if kind == 0:
+            pos = rng.uniform(-100, 100, (n, 3))
+        elif kind == 1:
+            centers = rng.uniform(-500, 500, (max(1, n // 50), 3))
+            pos = centers[rng.randint(0, len(centers), n)] + rng.normal(0, 0.5, (n, 3))
+        elif kind == 2:
+            pos = rng.normal(0, 1, (n, 3)) * np.array([300.0, 3.0, 0.03])
+        else:
+            pos = rng.uniform(-50, 50, (n, 3))
+            k = min(n // 2, 40)  # tight pairs: separation 1e-6 .. 1e-9 of the box
+            pos[n - k:] = pos[:k] + rng.uniform(-1, 1, (k, 3)) * 10.0 ** rng.uniform(-7, -4, (k, 1))
+        mass = rng.uniform(0.1, 5.0, n)
+        pos = np.ascontiguousarray(pos)
+        G, eps, theta = 0.7, float(rng.choice([0.05, 1.0, 4.0])), float(rng.choice([0.3, 0.5, 0.9]))
+        sim = _bh(gpu, pos, np.zeros_like(pos), mass, G, eps, theta=theta)
+        sim.build_tree()
+        st = sim.tree_stats()
+        b = oracle.compute_bounds(pos)
+        nd = oracle.NodeArrays(4 * n + 4096)
+        nn = oracle.build_octree(pos, mass, b, nd, cap=oracle.UNCAPPED)
+        level, key = oracle.tree_cells(nd, nn)
+        assert st["bounds"] == b and st["num_nodes"] == nn and st["max_depth"] == int(level.max()), (case, n, st, nn)
+        glevel, gkey = sim.cells()
+        assert np.array_equal(np.bincount(glevel, minlength=48), np.bincount(level, minlength=48)), case
+        sel_g, sel_o = glevel <= 21, level <= 21
+        assert np.array_equal(_sorted_cells(glevel[sel_g], gkey[sel_g]), _sorted_cells(level[sel_o], key[sel_o])), case
+        hi, lo = sim.morton_keys()
+        ohi, olo = oracle.body_keys(pos, b)
+        assert np.array_equal(hi, ohi) and np.array_equal(lo, olo), case
+        acc = sim.accelerations()
+        ref = oracle.compute_forces_barnes_hut(pos, mass, nd, nn, theta, G, eps)
+        bound = 2e-4 * (np.abs(ref).max() + 1e-30) + 4 * np.spacing(np.float32(np.abs(pos).max())) * G * mass.max() / eps ** 3
+        err = np.abs(acc - ref).max()
+        worst = max(worst, err / bound)
+        assert err <= bound, (case, n, kind, err, bound)
+        sim.close()
+    print("stress: worst error / stated bound =", worst)
