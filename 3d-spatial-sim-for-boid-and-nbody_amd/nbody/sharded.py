@@ -81,7 +81,8 @@ def create_sharded_simulation(positions, velocities, masses, G, softening, dampi
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    import torch
+    local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
     eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local)
     return ShardedBarnesHut(eng, len(positions), rank, world, dist if world > 1 else None)
 

@@ -191,11 +191,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev = local % max(1, ndev)  # == LOCAL_RANK on a real node; lets ranks share a GPU in rehearsals
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        torch.cuda.set_device(dev)
+        backend = os.environ.get("NBMI_BENCH_BACKEND", "nccl")  # "gloo": 1-GPU rehearsal of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
 
@@ -217,8 +223,8 @@ def main():
             sim = sharded.engine.sim
             step = lambda k: sharded.step(dt, k)  # noqa: E731
         else:
-            sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=local) if method == "barnes_hut"
-                   else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=local))
+            sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=dev) if method == "barnes_hut"
+                   else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=dev))
             step = lambda k: sim.step_many(dt, k)  # noqa: E731
 
     def fence():
