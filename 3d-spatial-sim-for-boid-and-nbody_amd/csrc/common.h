@@ -36,11 +36,4 @@ size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit);
 hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit,
                               int end_bit, hipStream_t s);
-size_t scan_i32_temp_bytes(size_t n);
-hipError_t exclusive_scan_i32(void *temp, size_t temp_bytes, const int32_t *in, int32_t *out, size_t n,
-                              hipStream_t s);
-size_t scan_moment_temp_bytes(size_t n);
-hipError_t exclusive_scan_moment(void *temp, size_t temp_bytes, const Moment *in, Moment *out, size_t n,
-                                 hipStream_t s);
-
 }  // namespace nbmi

@@ -207,21 +207,17 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// K5: gather bodies into key order: fp32 {x,y,z,G*m} for the walk / leaves, low key word,
-// float64 moments {m, m x, m y, m z} for the COM prefix sums.
+// K5: gather bodies into key order: fp32 {x,y,z,G*m} (walk / leaf data, and the input of the
+// moment prefix sums) and the low key word.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_gather(Bodies cur, const uint32_t *__restrict__ perm,
                                                    const uint64_t *__restrict__ key_lo, int64_t n, double G,
-                                                   float4 *__restrict__ posm_s, uint64_t *__restrict__ lo_s,
-                                                   Moment *__restrict__ W) {
+                                                   float4 *__restrict__ posm_s, uint64_t *__restrict__ lo_s) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r == 0) W[n] = Moment{0.0, 0.0, 0.0, 0.0};
     if (r >= n) return;
     const uint32_t j = perm[r];
-    const double px = cur.x[j], py = cur.y[j], pz = cur.z[j], m = cur.m[j];
-    posm_s[r] = make_float4((float)px, (float)py, (float)pz, (float)(G * m));
+    posm_s[r] = make_float4((float)cur.x[j], (float)cur.y[j], (float)cur.z[j], (float)(G * cur.m[j]));
     lo_s[r] = key_lo[j];
-    W[r] = Moment{m, m * px, m * py, m * pz};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -238,6 +234,122 @@ __global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ h
     const int dp = (r > 0) ? cpl_digits(hi_s[r - 1], lo_s[r - 1], h, l) : -1;
     delta[r] = d;
     cnt[r] = d > dp ? d - dp : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// K7: exclusive prefix sums over the sorted bodies, three hand-written phases (reduce per tile ->
+// scan of the tile sums -> scan inside the tiles).  One pass produces both
+//   S[r]   = sum_{i<r} {G m, G m x, G m y, G m z}   (float64, formed on the fly from posm_s), and
+//   Pex[r] = sum_{i<r} cnt[i]
+// with S[n], Pex[n] = totals.  (rocPRIM's look-back scan of the 32-byte struct ran at ~1 TB/s.)
+// ---------------------------------------------------------------------------------------
+constexpr int kScanItems = 8;                      // elements per thread
+constexpr int kScanTile = kBlock * kScanItems;     // 2048 elements per block
+
+struct ScanVal {
+    double m, x, y, z;
+    int c;
+};
+__device__ __forceinline__ ScanVal sv_zero() { return ScanVal{0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ ScanVal sv_add(const ScanVal &a, const ScanVal &b) {
+    return ScanVal{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z, a.c + b.c};
+}
+__device__ __forceinline__ ScanVal sv_load(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
+                                           int64_t i, int64_t n) {
+    if (i >= n) return sv_zero();
+    const float4 p = posm_s[i];
+    const double gm = (double)p.w;
+    return ScanVal{gm, gm * (double)p.x, gm * (double)p.y, gm * (double)p.z, cnt[i]};
+}
+__device__ __forceinline__ ScanVal sv_shfl_up(const ScanVal &v, int d) {
+    return ScanVal{__shfl_up(v.m, d), __shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.c, d)};
+}
+// inclusive scan across the 256 threads of a block; returns the thread's inclusive value and the
+// block total in `total`
+__device__ __forceinline__ ScanVal block_inclusive_scan(ScanVal v, ScanVal *lds /* kBlock/64 */, ScanVal &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const ScanVal o = sv_shfl_up(v, d);
+        if (lane >= d) v = sv_add(o, v);
+    }
+    if (lane == 63) lds[wave] = v;
+    __syncthreads();
+    ScanVal off = sv_zero();
+    total = sv_zero();
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (w < wave) off = sv_add(off, lds[w]);
+        total = sv_add(total, lds[w]);
+    }
+    __syncthreads();
+    return sv_add(off, v);
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
+                                                        int64_t n, ScanVal *__restrict__ tile_sum) {
+    __shared__ ScanVal lds[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    ScanVal acc = sv_zero();
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++)  // strided: coalesced loads
+        acc = sv_add(acc, sv_load(posm_s, cnt, base + (int64_t)k * kBlock + threadIdx.x, n));
+    ScanVal total;
+    (void)block_inclusive_scan(acc, lds, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// exclusive value of each thread from the block-inclusive ones (no floating-point subtraction)
+__device__ __forceinline__ ScanVal block_exclusive_from_inclusive(const ScanVal &inc, ScanVal *excl /* kBlock */) {
+    excl[threadIdx.x] = inc;
+    __syncthreads();
+    const ScanVal r = threadIdx.x > 0 ? excl[threadIdx.x - 1] : sv_zero();
+    __syncthreads();
+    return r;
+}
+
+// one block: exclusive scan of the tile sums in place (sequential over chunks of kBlock tiles)
+__global__ __launch_bounds__(kBlock) void k_scan_tiles(ScanVal *__restrict__ tile_sum, int64_t ntiles) {
+    __shared__ ScanVal lds[kBlock / 64];
+    __shared__ ScanVal excl[kBlock];
+    ScanVal carry = sv_zero();
+    for (int64_t base = 0; base < ntiles; base += kBlock) {
+        const int64_t i = base + threadIdx.x;
+        const ScanVal v = i < ntiles ? tile_sum[i] : sv_zero();
+        ScanVal total;
+        const ScanVal inc = block_inclusive_scan(v, lds, total);
+        const ScanVal ex = block_exclusive_from_inclusive(inc, excl);
+        if (i < ntiles) tile_sum[i] = sv_add(carry, ex);
+        carry = sv_add(carry, total);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
+                                                       int64_t n, const ScanVal *__restrict__ tile_off,
+                                                       Moment *__restrict__ S, int32_t *__restrict__ Pex) {
+    __shared__ ScanVal lds[kBlock / 64];
+    __shared__ ScanVal excl[kBlock];
+    // blocked layout: each thread owns kScanItems consecutive elements
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    ScanVal v[kScanItems];
+    ScanVal sum = sv_zero();
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        v[k] = sv_load(posm_s, cnt, base + k, n);
+        sum = sv_add(sum, v[k]);
+    }
+    ScanVal total;
+    const ScanVal inc = block_inclusive_scan(sum, lds, total);
+    ScanVal run = sv_add(tile_off[blockIdx.x], block_exclusive_from_inclusive(inc, excl));
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        const int64_t i = base + k;
+        if (i <= n) {  // entry n receives the grand totals
+            S[i] = Moment{run.m, run.x, run.y, run.z};
+            Pex[i] = run.c;
+        }
+        run = sv_add(run, v[k]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -352,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
     const int64_t idx = r + q;
     Node nd;
     nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
-    nd.gm = (float)(G * M);
+    nd.gm = (float)M;  // the moments are sums of G*m
     nd.s2t = (float)(size * size * inv_theta2);
     nd.next_off = (unsigned)((e + (int64_t)Pex[e]) << 5);
     nd.seq_off = (unsigned)((idx + 1) << 5);
@@ -743,15 +855,16 @@ struct nbmi_sim {
     uint32_t *idx = nullptr, *perm = nullptr;
     int32_t *delta = nullptr, *cnt = nullptr, *Pex = nullptr;
     float4 *posm_s = nullptr;
-    Moment *W = nullptr, *S = nullptr;
+    Moment *S = nullptr;
+    ScanVal *tile_sum = nullptr;
     Node *nodes = nullptr;
     uint8_t *node_level = nullptr;
     int32_t *cell_r = nullptr;  // internal-cell list: first body and level
     uint8_t *cell_lev = nullptr;
     int64_t node_capacity = 0;
     TreeInfo *info = nullptr;  // device
-    void *tmp_sort = nullptr, *tmp_scan_i = nullptr, *tmp_scan_m = nullptr;
-    size_t tmp_sort_bytes = 0, tmp_scan_i_bytes = 0, tmp_scan_m_bytes = 0;
+    void *tmp_sort = nullptr;
+    size_t tmp_sort_bytes = 0;
     float *colors = nullptr;  // (N,3) original order
     void *stage = nullptr;    // getter staging, 3N doubles
     bool tree_valid = false;
@@ -812,10 +925,14 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
                                             (size_t)n, 0, 63, st));
     k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, n);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
-    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s, s->W);
+    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s);
     k_delta<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, n, s->delta, s->cnt);
-    NBMI_HIP_CHECK(nbmi::exclusive_scan_i32(s->tmp_scan_i, s->tmp_scan_i_bytes, s->cnt, s->Pex, (size_t)n + 1, st));
-    NBMI_HIP_CHECK(nbmi::exclusive_scan_moment(s->tmp_scan_m, s->tmp_scan_m_bytes, s->W, s->S, (size_t)n + 1, st));
+    {
+        const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
+        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(s->posm_s, s->cnt, n, s->tile_sum);
+        k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
+        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(s->posm_s, s->cnt, n, s->tile_sum, s->S, s->Pex);
+    }
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->posm_s, n, s->node_capacity, s->nodes,
@@ -941,20 +1058,14 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
-            dev_alloc(s, &s->W, n + 1) || dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->nodes, s->node_capacity) ||
+            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity) ||
             dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
             dev_alloc(s, &s->cell_lev, s->node_capacity - n))
             return -2;
         s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
-        s->tmp_scan_i_bytes = nbmi::scan_i32_temp_bytes((size_t)n + 1);
-        s->tmp_scan_m_bytes = nbmi::scan_moment_temp_bytes((size_t)n + 1);
         char *t = nullptr;
         if (dev_alloc(s, &t, s->tmp_sort_bytes + 256)) return -2;
         s->tmp_sort = t;
-        if (dev_alloc(s, &t, s->tmp_scan_i_bytes + 256)) return -2;
-        s->tmp_scan_i = t;
-        if (dev_alloc(s, &t, s->tmp_scan_m_bytes + 256)) return -2;
-        s->tmp_scan_m = t;
     }
     // upload AoS host arrays through the staging buffer and split to SoA
     double *dpos = (double *)s->stage, *dvel = dpos + 3 * n, *dm = dvel + 3 * n;

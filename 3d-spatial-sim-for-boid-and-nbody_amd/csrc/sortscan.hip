@@ -1,4 +1,4 @@
-// Device radix sort and prefix scans used by the octree build and the boids grid.
+// Device radix sorts used by the octree build and the boids grid.
 // These are plain library primitives (rocPRIM); the hand-written kernels live in nbmi.hip /
 // bdmi.hip.  Kept in their own translation unit because the rocPRIM templates dominate
 // compile time.
@@ -8,12 +8,6 @@
 #include "common.h"
 
 namespace nbmi {
-
-struct MomentPlus {
-    __host__ __device__ Moment operator()(const Moment &a, const Moment &b) const {
-        return Moment{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z};
-    }
-};
 
 size_t sort_pairs_temp_bytes(size_t n, int begin_bit, int end_bit) {
     size_t bytes = 0;
@@ -41,31 +35,6 @@ hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit,
                               hipStream_t s) {
     return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
-}
-
-size_t scan_i32_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    (void)rocprim::exclusive_scan<rocprim::default_config, const int32_t *, int32_t *, int32_t,
-                                  rocprim::plus<int32_t>>(nullptr, bytes, nullptr, nullptr, 0, n,
-                                                          rocprim::plus<int32_t>(), 0);
-    return bytes;
-}
-
-hipError_t exclusive_scan_i32(void *temp, size_t temp_bytes, const int32_t *in, int32_t *out, size_t n,
-                              hipStream_t s) {
-    return rocprim::exclusive_scan(temp, temp_bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), s);
-}
-
-size_t scan_moment_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    (void)rocprim::exclusive_scan<rocprim::default_config, const Moment *, Moment *, Moment, MomentPlus>(
-        nullptr, bytes, nullptr, nullptr, Moment{0, 0, 0, 0}, n, MomentPlus(), 0);
-    return bytes;
-}
-
-hipError_t exclusive_scan_moment(void *temp, size_t temp_bytes, const Moment *in, Moment *out, size_t n,
-                                 hipStream_t s) {
-    return rocprim::exclusive_scan(temp, temp_bytes, in, out, Moment{0, 0, 0, 0}, n, MomentPlus(), s);
 }
 
 }  // namespace nbmi
