@@ -80,13 +80,27 @@ __global__ __launch_bounds__(kBlock) void k_reorder(Boids a, BoidsAoS b, const u
 __global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
                                                   uint32_t *__restrict__ occ, int2 *__restrict__ cell_range) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n) return;
-    const uint32_t c = keys_s[r];
-    if (r > 0 && keys_s[r - 1] == c) return;  // not the first boid of its cell
-    int64_t e = r + 1;
-    while (e < n && keys_s[e] == c) e++;
-    cell_range[c] = make_int2((int)r, (int)e);
-    atomicOr(&occ[c >> 5], 1u << (c & 31));
+    const int lane = threadIdx.x & 63;
+    uint32_t word = 0xffffffffu, bits = 0u;
+    if (r < n) {
+        const uint32_t c = keys_s[r];
+        word = c >> 5;
+        if (r == 0 || keys_s[r - 1] != c) {  // first boid of its cell
+            int64_t e = r + 1;
+            while (e < n && keys_s[e] == c) e++;
+            cell_range[c] = make_int2((int)r, (int)e);
+            bits = 1u << (c & 31);
+        }
+    }
+    // cells of one occupancy word are adjacent in the sorted order: OR their bits inside the wave
+    // (segmented by word) so that only the first lane of each segment issues an atomic
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ob = __shfl_down(bits, d), ow = __shfl_down(word, d);
+        if (lane + d < 64 && ow == word) bits |= ob;
+    }
+    const uint32_t pw = __shfl_up(word, 1);
+    if (bits != 0u && (lane == 0 || pw != word)) atomicOr(&occ[word], bits);
 }
 
 // number of non-empty cells of the last grid; on demand only (bdmi_grid_info), one atomic per block
