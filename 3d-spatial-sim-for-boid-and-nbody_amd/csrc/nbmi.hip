@@ -1126,6 +1126,10 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
         return NBMI_ERR_ARG;
     }
     if (s->n == 0) return 0;
+    if (substeps > 1 && (s->shard_begin != 0 || s->shard_end != s->n)) {
+        nbmi::set_error("nbmi_step: a sharded handle needs nbmi_import_ranks between steps (substeps must be 1)");
+        return NBMI_ERR_ARG;
+    }
     for (int k = 0; k < substeps; k++) {
         if (s->method == NBMI_METHOD_BARNES_HUT) {
             const int evb = s->timers ? 0 : -1;

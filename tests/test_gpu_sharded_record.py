@@ -37,6 +37,9 @@ def test_virtual_shards_bit_identical_to_single_handle(gpu):
     for e in engines:
         assert np.array_equal(e.sim.get_positions_f64(), ref_p)
         assert np.array_equal(e.sim.get_velocities(), ref_v)
+    # a sharded handle refuses multi-substep calls (the other ranks' rows would be missing)
+    with pytest.raises(RuntimeError, match="sharded handle"):
+        engines[0].sim.step_many(0.05, 2)
     # world_size 1 goes through the same class without any exchange
     one = ShardedBarnesHut(HipShardEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0), n, 0, 1)
     one.step(0.05, 5)
