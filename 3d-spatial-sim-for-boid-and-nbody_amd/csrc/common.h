@@ -36,4 +36,11 @@ size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit);
 hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit,
                               int end_bit, hipStream_t s);
+
+// One body of a key-sorted run as it travels between GPUs (multi-GPU run exchange): the two
+// octant-path key words and the fp32 {x, y, z, G*m} the octree is built from.  32 bytes.
+struct RunRec {
+    uint64_t hi, lo;
+    float x, y, z, gm;
+};
 }  // namespace nbmi

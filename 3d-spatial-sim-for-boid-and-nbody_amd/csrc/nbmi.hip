@@ -807,6 +807,12 @@ __global__ __launch_bounds__(kBlock) void k_keys_to_orig(const uint64_t *__restr
     out_hi[o] = hi_s[r];
     out_lo[o] = lo_s[r];
 }
+__global__ __launch_bounds__(kBlock) void k_order(const uint32_t *__restrict__ perm, const int32_t *__restrict__ id,
+                                                  int64_t n, int32_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r < n) out[r] = id[perm[r]];
+}
+
 __global__ __launch_bounds__(kBlock) void k_cells(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
                                                   const uint64_t *__restrict__ hi_s, int64_t num_nodes,
                                                   int32_t *__restrict__ level, uint64_t *__restrict__ key) {
@@ -841,6 +847,84 @@ inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 }  // namespace
 
 // =========================================================================================
+// multi-GPU run exchange: a rank's key-sorted bodies as 32-byte records and back to the arrays
+// the tree kernels read.  Padding records carry the all-ones key so they merge to the very end.
+// =========================================================================================
+using nbmi::RunRec;
+__global__ __launch_bounds__(kBlock) void k_pack_run(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
+                                                     const float4 *__restrict__ posm_s, int64_t n, int64_t rows,
+                                                     RunRec *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    RunRec q;
+    if (r < n) {
+        const float4 p = posm_s[r];
+        q.hi = hi_s[r]; q.lo = lo_s[r];
+        q.x = p.x; q.y = p.y; q.z = p.z; q.gm = p.w;
+    } else {
+        q.hi = ~0ull; q.lo = ~0ull;
+        q.x = q.y = q.z = q.gm = 0.f;
+    }
+    out[r] = q;
+}
+
+// Merge of the `world` gathered runs by ranking: a record's position in the merged order is its
+// index in its own run plus, for every other run, the number of records that sort before it (ties:
+// lower run first, so the order is total and every rank unique).  All `world - 1` binary searches
+// of a thread advance together (independent loads in flight), and the record is scattered straight
+// into the arrays the tree kernels read.  Padding records (all-ones keys) rank after every real
+// one and are dropped; `nt` real records must come out, else info->error = 2.
+constexpr int kPeers = 8;  // searches interleaved per pass
+__global__ __launch_bounds__(kBlock) void k_merge_ranks(const RunRec *__restrict__ runs, int world, int R, int64_t nt,
+                                                        int steps, uint64_t *__restrict__ hi, uint64_t *__restrict__ lo,
+                                                        float4 *__restrict__ posm, TreeInfo *info) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)world * R) return;
+    const int a = (int)(t / R);
+    const int i = (int)(t - (int64_t)a * R);
+    const RunRec me = runs[t];
+    if (me.hi == ~0ull && me.lo == ~0ull) return;
+    int64_t rank = i;
+    for (int b0 = 0; b0 < world; b0 += kPeers) {
+        int first[kPeers], len[kPeers];
+#pragma unroll
+        for (int k = 0; k < kPeers; k++) {
+            first[k] = 0;
+            len[k] = (b0 + k < world && b0 + k != a) ? R : 0;
+        }
+        for (int s = 0; s < steps; s++) {
+            ulonglong2 key[kPeers];
+#pragma unroll
+            for (int k = 0; k < kPeers; k++) {
+                int mid = first[k] + (len[k] >> 1);
+                mid = mid < R ? mid : R - 1;
+                const int b = b0 + k < world ? b0 + k : a;
+                key[k] = *reinterpret_cast<const ulonglong2 *>(&runs[(int64_t)b * R + mid]);
+            }
+#pragma unroll
+            for (int k = 0; k < kPeers; k++) {
+                const int half = len[k] >> 1;
+                const bool key_lt_me = key[k].x < me.hi || (key[k].x == me.hi && key[k].y < me.lo);
+                const bool key_eq_me = key[k].x == me.hi && key[k].y == me.lo;
+                // runs before mine count their records <= me, runs after mine those < me
+                const bool before = (key_lt_me || (key_eq_me && b0 + k < a)) && len[k] > 0;
+                first[k] = before ? first[k] + half + 1 : first[k];
+                len[k] = before ? len[k] - half - 1 : half;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kPeers; k++) rank += first[k];
+    }
+    if (rank >= nt) {
+        info->error = 2;
+        return;
+    }
+    hi[rank] = me.hi;
+    lo[rank] = me.lo;
+    posm[rank] = make_float4(me.x, me.y, me.z, me.gm);
+}
+
+// =========================================================================================
 // handle
 // =========================================================================================
 struct nbmi_sim {
@@ -869,6 +953,12 @@ struct nbmi_sim {
     void *stage = nullptr;    // getter staging, 3N doubles
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
+    // octree inputs in key order.  Normally the handle's own sorted arrays (nt == n); with the run
+    // exchange enabled, the merge of every rank's run (nt = bodies of the whole system).
+    int64_t nt = 0;
+    uint64_t *t_hi = nullptr, *t_lo = nullptr;
+    float4 *t_posm = nullptr;
+    int world = 0;  // > 0: run exchange enabled
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     // timers
     bool timers = false;
@@ -908,17 +998,27 @@ int check_handle(nbmi_sim *s) {
     return 0;
 }
 
-// Enqueue bounds -> keys -> sort -> tie fix -> gather -> delta -> scans -> node emission.
-int enqueue_tree(nbmi_sim *s, int ev_base) {
+// The octree build in three enqueue stages (one after the other for a single-GPU step; the
+// multi-GPU run exchange puts its two collectives between them):
+//   enqueue_maxabs      reset the tree header, max |coordinate| of the handle's own bodies
+//   enqueue_local_sort  keys -> sort -> tie fix -> gather: the handle's bodies in key order
+//   enqueue_global_tree delta -> scans -> node emission over the nt bodies of t_hi/t_lo/t_posm
+int enqueue_maxabs(nbmi_sim *s) {
     const int64_t n = s->n;
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf];
-    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], st));
     // reset maxabs/num_nodes/max_level/error (keep counters)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     int gb = nblocks(n);
     if (gb > 256) gb = 256;  // one same-address atomic per block: keep them few
     k_maxabs<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info);
+    return 0;
+}
+
+int enqueue_local_sort(nbmi_sim *s, int ev_base) {
+    const int64_t n = s->n;
+    hipStream_t st = s->stream;
+    Bodies cur = s->buf[s->curbuf];
     k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
@@ -926,23 +1026,42 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, n);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
     k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s);
-    k_delta<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->lo_s, n, s->delta, s->cnt);
+    return 0;
+}
+
+int enqueue_global_tree(nbmi_sim *s) {
+    const int64_t n = s->nt;
+    hipStream_t st = s->stream;
+    k_delta<<<nblocks(n), kBlock, 0, st>>>(s->t_hi, s->t_lo, n, s->delta, s->cnt);
     {
         const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
-        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(s->posm_s, s->cnt, n, s->tile_sum);
+        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(s->t_posm, s->cnt, n, s->tile_sum);
         k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
-        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(s->posm_s, s->cnt, n, s->tile_sum, s->S, s->Pex);
+        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(s->t_posm, s->cnt, n, s->tile_sum, s->S, s->Pex);
     }
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
-    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->posm_s, n, s->node_capacity, s->nodes,
+    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->node_capacity, s->nodes,
                                                  s->node_level, s->cell_r, s->cell_lev, s->info);
     // one thread per internal cell; the count lives on the device, so launch for the row budget
-    k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->hi_s, s->lo_s, s->Pex, s->S, s->cell_r, s->cell_lev,
+    k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
                                                                   n, s->G, inv_theta2, s->node_capacity, s->nodes,
                                                                   s->node_level, s->info);
-    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], st));
     NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Single-GPU build: the tree over the handle's own bodies.
+int enqueue_tree(nbmi_sim *s, int ev_base) {
+    if (s->world > 0) {
+        nbmi::set_error("this handle is in run-exchange mode: use the nbmi_exchange_* calls");
+        return NBMI_ERR_ARG;
+    }
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+    if (int rc = enqueue_maxabs(s)) return rc;
+    if (int rc = enqueue_local_sort(s, ev_base)) return rc;
+    if (int rc = enqueue_global_tree(s)) return rc;
+    if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], s->stream));
     s->tree_valid = true;
     return 0;
 }
@@ -1006,6 +1125,10 @@ int check_device_error(nbmi_sim *s) {
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (h.error == 2) {
+        nbmi::set_error("run exchange: the gathered runs do not hold the %lld bodies announced", (long long)s->nt);
+        return NBMI_ERR_ARG;
+    }
     if (h.error) {
         nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference)",
                         (long long)h.num_nodes, (long long)s->node_capacity);
@@ -1079,6 +1202,10 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->shard_begin = 0;
     s->shard_end = n;
+    s->nt = n;
+    s->t_hi = s->hi_s;
+    s->t_lo = s->lo_s;
+    s->t_posm = s->posm_s;
     return 0;
 }
 
@@ -1274,9 +1401,9 @@ int nbmi_tree_stats(nbmi_sim *s, int64_t *num_nodes, int32_t *max_depth, double 
         return 0;
     }
     if (max_depth) {
-        int gb = nblocks(s->n);
+        int gb = nblocks(s->nt);
         if (gb > 64) gb = 64;
-        k_max_level<<<gb, kBlock, 0, s->stream>>>(s->delta, s->n, s->info);
+        k_max_level<<<gb, kBlock, 0, s->stream>>>(s->delta, s->nt, s->info);
         NBMI_HIP_CHECK(hipGetLastError());
     }
     TreeInfo h;
@@ -1310,6 +1437,22 @@ int nbmi_get_keys(nbmi_sim *s, uint64_t *key_hi, uint64_t *key_lo) {
     return 0;
 }
 
+int nbmi_get_order(nbmi_sim *s, int32_t *order) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT || !s->tree_valid) {
+        nbmi::set_error("nbmi_get_order: call nbmi_build_tree first");
+        return NBMI_ERR_ARG;
+    }
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!order) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    k_order<<<nblocks(n), kBlock, 0, s->stream>>>(s->perm, s->buf[s->curbuf].id, n, (int32_t *)s->stage);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(order, s->stage, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
 int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity) {
     if (int rc = check_handle(s)) return rc;
     if (s->method != NBMI_METHOD_BARNES_HUT || !s->tree_valid) {
@@ -1327,7 +1470,7 @@ int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity)
     uint64_t *dk = nullptr;
     NBMI_HIP_CHECK(hipMalloc((void **)&dl, (size_t)nn * 4));
     NBMI_HIP_CHECK(hipMalloc((void **)&dk, (size_t)nn * 8));
-    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->node_level, s->hi_s, nn, dl, dk);
+    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->node_level, s->t_hi, nn, dl, dk);
     hipError_t e1 = hipMemcpyAsync(level, dl, (size_t)nn * 4, hipMemcpyDeviceToHost, s->stream);
     hipError_t e2 = hipMemcpyAsync(key, dk, (size_t)nn * 8, hipMemcpyDeviceToHost, s->stream);
     hipError_t e3 = hipStreamSynchronize(s->stream);
@@ -1401,6 +1544,75 @@ int nbmi_import_ranks(nbmi_sim *s, const void *dev_rows, int64_t begin, int64_t 
     k_unpack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], begin, end, (const double *)dev_rows);
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->tree_valid = false;
+    return 0;
+}
+
+int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_rows) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
+    if (s->world > 0) { nbmi::set_error("nbmi_exchange_enable: already enabled"); return NBMI_ERR_ARG; }
+    if (world < 1 || run_rows < s->n || n_total < s->n || n_total > (int64_t)world * run_rows || n_total > 30000000) {
+        nbmi::set_error("nbmi_exchange_enable: bad sizes (n=%lld, n_total=%lld, world=%d, run_rows=%lld)",
+                        (long long)s->n, (long long)n_total, world, (long long)run_rows);
+        return NBMI_ERR_ARG;
+    }
+    const int64_t nt = n_total;
+    s->node_capacity = 4 * nt + 4096;
+    // tree workspace for the whole system (the n-sized arrays of nbmi_create stay for the local sort)
+    if (dev_alloc(s, &s->t_hi, nt) || dev_alloc(s, &s->t_lo, nt) || dev_alloc(s, &s->t_posm, nt) ||
+        dev_alloc(s, &s->delta, nt) || dev_alloc(s, &s->cnt, nt + 1) || dev_alloc(s, &s->Pex, nt + 1) ||
+        dev_alloc(s, &s->S, nt + 1) || dev_alloc(s, &s->tile_sum, (nt + 1) / kScanTile + 2) ||
+        dev_alloc(s, &s->nodes, s->node_capacity) || dev_alloc(s, &s->node_level, s->node_capacity) ||
+        dev_alloc(s, &s->cell_r, s->node_capacity - nt) || dev_alloc(s, &s->cell_lev, s->node_capacity - nt))
+        return NBMI_ERR_HIP;
+    s->nt = nt;
+    s->world = world;
+    s->tree_valid = false;
+    return 0;
+}
+
+int nbmi_exchange_maxabs(nbmi_sim *s, void *dev_maxabs) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->world <= 0 || !dev_maxabs) { nbmi::set_error("nbmi_exchange_maxabs: exchange not enabled / null buffer"); return NBMI_ERR_ARG; }
+    if (int rc = enqueue_maxabs(s)) return rc;
+    // a non-negative double and its bit pattern order the same way: the word IS the double
+    NBMI_HIP_CHECK(hipMemcpyAsync(dev_maxabs, &s->info->maxabs_bits, 8, hipMemcpyDeviceToDevice, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_exchange_export(nbmi_sim *s, const void *dev_maxabs, void *dev_run, int64_t run_rows) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->world <= 0 || !dev_maxabs || !dev_run || run_rows < s->n) {
+        nbmi::set_error("nbmi_exchange_export: exchange not enabled / bad buffers");
+        return NBMI_ERR_ARG;
+    }
+    NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, s->stream));
+    if (s->n > 0)
+        if (int rc = enqueue_local_sort(s, -1)) return rc;
+    k_pack_run<<<nblocks(run_rows), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->posm_s, s->n, run_rows, (RunRec *)dev_run);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_exchange_step(nbmi_sim *s, const void *dev_runs, int world, int64_t run_rows, double dt) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->world <= 0 || world != s->world || !dev_runs || (int64_t)world * run_rows < s->nt) {
+        nbmi::set_error("nbmi_exchange_step: exchange not enabled / sizes differ from nbmi_exchange_enable");
+        return NBMI_ERR_ARG;
+    }
+    hipStream_t st = s->stream;
+    const int64_t rows = (int64_t)world * run_rows;
+    int steps = 1;
+    while ((1ll << steps) <= run_rows) steps++;  // iterations that empty a search range of run_rows
+    k_merge_ranks<<<nblocks(rows), kBlock, 0, st>>>((const RunRec *)dev_runs, world, (int)run_rows, s->nt, steps, s->t_hi,
+                                                    s->t_lo, s->t_posm, s->info);
+    if (int rc = enqueue_global_tree(s)) return rc;
+    if (s->n > 0)
+        if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
+    s->curbuf ^= 1;
     s->tree_valid = false;
     return 0;
 }

@@ -41,6 +41,11 @@ PROTOTYPES = {
     "nbmi_set_shard": (C.c_int, [_vp, _i64, _i64]),
     "nbmi_export_shard": (C.c_int, [_vp, _vp]),
     "nbmi_import_ranks": (C.c_int, [_vp, _vp, _i64, _i64]),
+    "nbmi_get_order": (C.c_int, [_vp, _vp]),
+    "nbmi_exchange_enable": (C.c_int, [_vp, _i64, C.c_int, _i64]),
+    "nbmi_exchange_maxabs": (C.c_int, [_vp, _vp]),
+    "nbmi_exchange_export": (C.c_int, [_vp, _vp, _vp, _i64]),
+    "nbmi_exchange_step": (C.c_int, [_vp, _vp, C.c_int, _i64, _dbl]),
     "nbmi_stream": (_vp, [_vp]),
     "bdmi_create": (_vp, [_i64, _vp, _vp, _vp, _vp, C.c_int]),
     "bdmi_destroy": (None, [_vp]),

@@ -217,7 +217,28 @@ class HIPBarnesHutSimulation(_HIPSimulation):
                     window_misses={8 << w: int(out[3 + w]) for w in range(4)}, jumps=int(out[7]),
                     xcd_visits=[int(v) for v in out[8:16]])
 
+    def key_order(self):
+        """Body indices along the octant-key order of the last built tree."""
+        out = np.empty(self.n, dtype=np.int32)
+        _nat.check(self._lib.nbmi_get_order(self._h, _nat.ptr(out)), "nbmi_get_order")
+        return out
+
     # multi-GPU hooks (device pointers; see nbody/sharded.py)
+    def exchange_enable(self, n_total, world, run_rows):
+        _nat.check(self._lib.nbmi_exchange_enable(self._h, int(n_total), int(world), int(run_rows)),
+                   "nbmi_exchange_enable")
+
+    def exchange_maxabs(self, dev_ptr):
+        _nat.check(self._lib.nbmi_exchange_maxabs(self._h, int(dev_ptr)), "nbmi_exchange_maxabs")
+
+    def exchange_export(self, dev_maxabs, dev_run, run_rows):
+        _nat.check(self._lib.nbmi_exchange_export(self._h, int(dev_maxabs), int(dev_run), int(run_rows)),
+                   "nbmi_exchange_export")
+
+    def exchange_step(self, dev_runs, world, run_rows, dt):
+        _nat.check(self._lib.nbmi_exchange_step(self._h, int(dev_runs), int(world), int(run_rows), float(dt)),
+                   "nbmi_exchange_step")
+
     def set_shard(self, begin, end):
         _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")
 

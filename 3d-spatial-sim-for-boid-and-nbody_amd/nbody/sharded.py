@@ -1,11 +1,24 @@
 """Multi-GPU Barnes-Hut: one process per GPU, bodies sharded by octant-key range.
 
-The reference is single-device; this is new design.  Stage 1 ("replicate the tree",
-bit-identical to the 1-GPU result): every rank holds all N bodies and builds the full octree
-(the non-scaling part), walks + integrates only its contiguous range of key-sorted ranks, and one
-all-gather per step (RCCL over xGMI: ``torch.distributed`` backend "nccl") returns everybody's
-updated rows {x,y,z,vx,vy,vz,m,id} (64 B per body).  The force on a body depends only on the
-global tree and on its own state, so the result does not depend on the world size.
+The reference is single-device; this is new design, in two forms, both bit-identical
+to the 1-GPU result (the force on a body depends only on the global tree and on its own state):
+
+* **row exchange** (``ShardedBarnesHut``, stage 1, the default of ``create_sharded_simulation``):
+  every rank holds all N bodies, sorts and builds over all of them, integrates one contiguous
+  range of sorted ranks (always a compact region, whatever the bodies did), and all-gathers the
+  updated rows {x,y,z,vx,vy,vz,m,id} (64 B per body).
+* **run exchange** (``RunExchangeBarnesHut``, experimental): a rank OWNS a fixed set of bodies
+  (initially one contiguous range of the key order) and keeps their float64 state to itself.  Per
+  step: all-reduce MAX of one double (the root cube), local keys + local sort, all-gather of the
+  key-sorted runs (32 B per body: two key words + fp32 x,y,z,G m), merge of the ``world`` sorted
+  runs, octree over the whole system, walk + integrate the owned bodies.  Half the bytes on the
+  wire and no whole-system sort, but measured it only pays with body
+  MIGRATION: a body that leaves its owner's region keeps its owner, lands in a wave with other
+  emigrants from all over the system, and that one wave then walks ~64 bodies' worth of distinct
+  paths serially (walk 1.7 -> 5-7 ms after a single step at 4 x 1 M).  It is the stepping stone to
+  the locally-essential-tree exchange, not the production path.
+
+Collectives are ``torch.distributed`` calls on device buffers (backend "nccl" = RCCL over xGMI).
 
 ``ShardedBarnesHut`` is written against a small shard-engine interface so the collective logic
 can be exercised on CPU (gloo) with a stand-in engine:
@@ -74,17 +87,130 @@ class ShardedBarnesHut:
             self.engine.import_rows(self.full, self.n)
 
 
-def create_sharded_simulation(positions, velocities, masses, G, softening, damping, theta=0.5):
-    """Build a ShardedBarnesHut from the torch.distributed environment (RANK/LOCAL_RANK/WORLD_SIZE).
-    Every rank passes the same full arrays."""
+def create_sharded_simulation(positions, velocities, masses, G, softening, damping, theta=0.5, mode="rows"):
+    """Build the multi-GPU stepper from the torch.distributed environment (RANK/LOCAL_RANK/
+    WORLD_SIZE).  Every rank passes the same full arrays.  mode: "rows" (stage 1, replicated state)
+    or "runs" (experimental run exchange with fixed ownership)."""
     import os
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     import torch
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
-    eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local)
-    return ShardedBarnesHut(eng, len(positions), rank, world, dist if world > 1 else None)
+    if mode == "rows":
+        eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local)
+        return ShardedBarnesHut(eng, len(positions), rank, world, dist if world > 1 else None)
+    if mode != "runs":
+        raise ValueError(f"unknown sharding mode {mode!r}")
+    eng = HipRunEngine(positions, velocities, masses, G, softening, damping, theta, local, rank, world)
+    return RunExchangeBarnesHut(eng, rank, world, DistComm(dist) if world > 1 else None)
+
+
+class HipRunEngine:
+    """Owner engine of the run exchange: this rank's bodies in one libnbmi handle."""
+
+    def __init__(self, positions, velocities, masses, G, softening, damping, theta, device, rank, world):
+        import torch
+        from .gpu_backend import HIPBarnesHutSimulation
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.n_total = len(positions)
+        self.per, begin, end = shard_bounds(self.n_total, world, rank)
+        if world == 1:
+            self.ids = np.arange(self.n_total, dtype=np.int64)
+        else:
+            # initial owners: contiguous ranges of the key order (compact wave groups)
+            full = HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta, device=device)
+            full.build_tree()
+            self.ids = full.key_order()[begin:end].astype(np.int64)
+            full.close()
+        self.sim = HIPBarnesHutSimulation(np.asarray(positions)[self.ids], np.asarray(velocities)[self.ids],
+                                          np.asarray(masses)[self.ids], G, softening, damping, theta, device=device)
+        self.n = self.sim.n
+        self.world = world
+        self.sim.exchange_enable(self.n_total, world, self.per)
+
+    def new_maxabs(self):
+        return self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
+
+    def new_run(self, rows):
+        return self.torch.zeros((rows, 4), dtype=self.torch.int64, device=self.device)  # 32-byte records
+
+    def local_maxabs(self, out):
+        self.sim.exchange_maxabs(out.data_ptr())  # synchronises the library stream
+
+    def export_run(self, maxabs, out):
+        self.torch.cuda.current_stream(self.device).synchronize()  # all-reduce finished
+        self.sim.exchange_export(maxabs.data_ptr(), out.data_ptr(), out.shape[0])
+
+    def step_runs(self, full, dt):
+        self.torch.cuda.current_stream(self.device).synchronize()  # all-gather finished
+        self.sim.exchange_step(full.data_ptr(), self.world, full.shape[0] // self.world, dt)
+
+    def owned_state(self):
+        """(global ids, positions f64, velocities f64) of the owned bodies."""
+        return self.ids, self.sim.get_positions_f64(), self.sim.get_velocities()
+
+
+class RunExchangeBarnesHut:
+    """step() over `world` ranks with fixed body ownership; see the module docstring.
+    `comm` needs all_reduce_max(tensor) and all_gather(full, mine) (default: torch.distributed)."""
+
+    def __init__(self, engine, rank, world, comm=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        self.comm = comm
+        self.n = engine.n_total
+        self.per = engine.per
+        self.maxabs = engine.new_maxabs()
+        self.mine = engine.new_run(self.per)
+        self.full = engine.new_run(self.per * world) if world > 1 else self.mine
+
+    def step(self, dt, substeps=1):
+        e = self.engine
+        for _ in range(substeps):
+            e.local_maxabs(self.maxabs)
+            if self.world > 1:
+                self.comm.all_reduce_max(self.maxabs)
+            e.export_run(self.maxabs, self.mine)
+            if self.world > 1:
+                self.comm.all_gather(self.full, self.mine)
+            e.step_runs(self.full, dt)
+
+    def gather_state(self):
+        """Full (positions, velocities) float64 in the caller's original order, on every rank."""
+        ids, pos, vel = self.engine.owned_state()
+        if self.world == 1:
+            out_p, out_v = np.empty((self.n, 3)), np.empty((self.n, 3))
+            out_p[ids], out_v[ids] = pos, vel
+            return out_p, out_v
+        import torch
+        mine = torch.full((self.per, 7), -1.0, dtype=torch.float64)
+        mine[: len(ids), 0] = torch.from_numpy(ids.astype(np.float64))
+        mine[: len(ids), 1:4] = torch.from_numpy(pos)
+        mine[: len(ids), 4:7] = torch.from_numpy(vel)
+        dev = self.full.device
+        mine = mine.to(dev)
+        full = torch.empty((self.per * self.world, 7), dtype=torch.float64, device=dev)
+        self.comm.all_gather(full, mine)
+        rows = full.cpu().numpy()
+        rows = rows[rows[:, 0] >= 0]
+        out_p, out_v = np.empty((self.n, 3)), np.empty((self.n, 3))
+        gid = rows[:, 0].astype(np.int64)
+        out_p[gid], out_v[gid] = rows[:, 1:4], rows[:, 4:7]
+        return out_p, out_v
+
+
+class DistComm:
+    """The two collectives of the run exchange on torch.distributed."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_reduce_max(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+
+    def all_gather(self, full, mine):
+        self.dist.all_gather_into_tensor(full, mine)
 
 
 def unpack_rows(rows: np.ndarray):

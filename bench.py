@@ -9,7 +9,8 @@ fused kick-drift) with the bodies already resident in HBM.  Default workload = B
 (galaxy, 1 M bodies per GPU, theta 0.5, dt 0.05, G 0.07, eps 1.5, R 800; synthetic IC from the
 reference's generator restated in tools/presets.py, seed 42).  With N > 1 the work per GPU is
 fixed (weak scaling): N x 1 M bodies, every rank builds the full octree and walks its own
-key-range, one RCCL all-gather of the updated rows per step (nbody/sharded.py).
+key-range, one RCCL all-gather of the updated rows per step (nbody/sharded.py;
+NBMI_SHARD_MODE=runs selects the experimental fixed-ownership run exchange).
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
   roofline     - dominant kernel (k_walk): algorithmic bytes per launch / its mean duration,
@@ -219,7 +220,8 @@ def main():
         if world > 1:
             from nbody.sharded import create_sharded_simulation
             assert method == "barnes_hut"
-            sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta)
+            shard_mode = os.environ.get("NBMI_SHARD_MODE", "rows")  # "runs": experimental fixed-ownership exchange
+            sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode)
             sim = sharded.engine.sim
             step = lambda k: sharded.step(dt, k)  # noqa: E731
         else:
@@ -258,8 +260,11 @@ def main():
         "config": {"workload": args.workload, "distribution": dist_name.replace("_fast", ""),
                    "bodies_per_gpu": per_gpu, "bodies_total": n_total, "theta": theta, "dt": dt, "G": G,
                    "softening": eps, "spawn_radius": R, "method": method,
-                   "parallelism": "single GPU" if world == 1 else f"key-range shards x{world}, replicated tree, "
-                                                                   "1 all-gather/step"},
+                   "parallelism": "single GPU" if world == 1 else
+                                  (f"x{world}: fixed owners (initial key ranges), all-reduce max + all-gather of "
+                                   "sorted 32-B runs per step, merged whole-system octree per rank"
+                                   if os.environ.get("NBMI_SHARD_MODE", "rows") == "runs" else
+                                   f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows")},
     }
 
     if world == 1 and rank == 0:

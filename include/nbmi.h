@@ -89,6 +89,9 @@ int nbmi_tree_stats(nbmi_sim *sim, int64_t *num_nodes, int32_t *max_depth, doubl
  * key_hi = levels 1..21 (3 bits per level, level 1 most significant, digit =
  * x>=cx | (y>=cy)<<1 | (z>=cz)<<2 as get_octant, simulation.py:38-49), key_lo = levels 22..42. */
 int nbmi_get_keys(nbmi_sim *sim, uint64_t *key_hi, uint64_t *key_lo);
+/* Body indices in octant-key (octree DFS) order for the most recently built tree: order[r] = index,
+ * in the caller's numbering, of the r-th body along the key order. */
+int nbmi_get_order(nbmi_sim *sim, int32_t *order);
 /* (level, path key) of every node of the most recently built tree (num_nodes entries,
  * unspecified order).  Keys of levels > 21 are reported as UINT64_MAX. */
 int nbmi_get_cells(nbmi_sim *sim, int32_t *level, uint64_t *key, int64_t capacity);
@@ -110,6 +113,30 @@ int nbmi_walk_counters(nbmi_sim *sim, int64_t *out16);
 int nbmi_set_shard(nbmi_sim *sim, int64_t begin, int64_t end);
 int nbmi_export_shard(nbmi_sim *sim, void *dev_rows);                              /* (end-begin, 8) f64 */
 int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_t end);
+
+/* Multi-GPU, experimental second form ("run exchange"; see DESIGN.md section 6 for why it is not
+ * the default: fixed ownership without body migration degrades the walk).  Each rank's handle is created with nbmi_create over
+ * the bodies it OWNS (a fixed set; any n_r >= 0) and never sees other ranks' velocities.  Per step
+ * the host framework runs two collectives on device buffers between three library calls:
+ *
+ *   nbmi_exchange_maxabs(h, m)            m <- max |coordinate| of the owned bodies (1 double)
+ *        all-reduce MAX of m              (compute_bounds over the whole system, simulation.py:308-317)
+ *   nbmi_exchange_export(h, m, run, R)    keys + local sort of the owned bodies; run <- R 32-byte
+ *                                         records {key_hi, key_lo, x, y, z, G*m (fp32)} in key order,
+ *                                         padded with all-ones keys after the n_r real ones
+ *        all-gather of the runs           (world x R records)
+ *   nbmi_exchange_step(h, runs, W, R, dt) merge the W sorted runs (by ranking), build the octree of the whole
+ *                                         system from them, walk + integrate the owned bodies
+ *
+ * The octree equals the single-GPU one (same sorted sequence of fp32 bodies), a body's force does not
+ * depend on which bodies share its wave, so positions are bit-identical to a one-GPU run.
+ * nbmi_exchange_enable allocates the whole-system tree workspace; afterwards nbmi_step,
+ * nbmi_build_tree and nbmi_get_accelerations_f64 are refused on this handle.  Getters keep returning
+ * the owned bodies in the order they were passed to nbmi_create.  Pointers are DEVICE pointers. */
+int nbmi_exchange_enable(nbmi_sim *sim, int64_t n_total, int world, int64_t run_rows);
+int nbmi_exchange_maxabs(nbmi_sim *sim, void *dev_maxabs);
+int nbmi_exchange_export(nbmi_sim *sim, const void *dev_maxabs, void *dev_run, int64_t run_rows);
+int nbmi_exchange_step(nbmi_sim *sim, const void *dev_runs, int world, int64_t run_rows, double dt);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 

@@ -46,6 +46,122 @@ def test_virtual_shards_bit_identical_to_single_handle(gpu):
     assert np.array_equal(one.engine.sim.get_positions_f64(), ref_p)
 
 
+class _ThreadComm:
+    """all_reduce_max / all_gather between `world` Python threads that play the ranks."""
+
+    def __init__(self, world):
+        import threading
+        self.world, self.bar, self.slots = world, threading.Barrier(world), [None] * world
+
+    def bind(self, rank):
+        comm = self
+
+        class Bound:
+            def all_reduce_max(self, t):
+                import torch
+                comm.slots[rank] = t
+                comm.bar.wait()
+                m = torch.stack(list(comm.slots)).max(dim=0).values.clone()
+                comm.bar.wait()
+                t.copy_(m)
+                comm.bar.wait()
+
+            def all_gather(self, full, mine):
+                import torch
+                comm.slots[rank] = mine
+                comm.bar.wait()
+                full.copy_(torch.cat(list(comm.slots), dim=0))
+                torch.cuda.synchronize()
+                comm.bar.wait()
+
+        return Bound()
+
+
+def test_run_exchange_ranks_bit_identical_to_single_handle(gpu):
+    """Run exchange (fixed ownership, sorted runs all-gathered, merged, whole-system octree per rank):
+    three threads on one GPU play three ranks through RunExchangeBarnesHut.step itself, collectives
+    replaced by thread barriers.  Owned bodies must equal the one-handle run bit for bit."""
+    import threading
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from nbody.sharded import HipRunEngine, RunExchangeBarnesHut
+    g = golden("tree_collision_2048")
+    n = 2001  # ragged: the last rank owns fewer bodies, its run is padded
+    pos, vel, mass = g["pos"][:n], g["vel"][:n], g["mass"][:n] * np.linspace(0.5, 2.0, n)
+    G, eps = float(g["G"]), float(g["eps"])
+    world, steps, dt = 3, 6, 0.05
+    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
+    single.step_many(dt, steps)
+    ref_p, ref_v = single.get_positions_f64(), single.get_velocities()
+    stats = single.tree_stats()
+
+    comm = _ThreadComm(world)
+    engines = [HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, r, world) for r in range(world)]
+    assert sorted(np.concatenate([e.ids for e in engines]).tolist()) == list(range(n))
+    steppers = [RunExchangeBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    assert steppers[0].full.shape == (steppers[0].per * world, 4)
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            steppers[r].step(dt, steps)
+            out[r] = steppers[r].gather_state()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            comm.bar.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    for e in engines:
+        ids, p, v = e.owned_state()
+        assert np.array_equal(p, ref_p[ids]) and np.array_equal(v, ref_v[ids])
+        # every rank built the octree of the whole system
+        st = e.sim.tree_stats()
+        assert (st["num_nodes"], st["max_depth"], st["bounds"]) == (stats["num_nodes"], stats["max_depth"], stats["bounds"])
+    for r in range(world):
+        assert np.array_equal(out[r][0], ref_p) and np.array_equal(out[r][1], ref_v)
+    # an exchange handle refuses the single-GPU entry points
+    with pytest.raises(RuntimeError, match="run-exchange"):
+        engines[0].sim.step(dt)
+    # world 1 goes through the same calls with no collective
+    one = RunExchangeBarnesHut(HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, 0, 1), 0, 1)
+    one.step(dt, steps)
+    p1, v1 = one.gather_state()
+    assert np.array_equal(p1, ref_p) and np.array_equal(v1, ref_v)
+
+
+def test_run_exchange_100k_two_ranks(gpu):
+    """Bigger case through the merge path (runs of 50 k records, two ranks, sequential phases)."""
+    import torch
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from nbody.sharded import HipRunEngine, RunExchangeBarnesHut
+    from tools.presets import generate_distribution
+    np.random.seed(7)
+    pos, vel, mass = generate_distribution("galaxy", 100_000, 500.0, 0.15)
+    G, eps = 0.15, 3.0
+    world, dt = 2, 0.05
+    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
+    single.step_many(dt, 3)
+    ref_p = single.get_positions_f64()
+    engines = [HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, r, world) for r in range(world)]
+    st = [RunExchangeBarnesHut(e, r, world, None) for r, e in enumerate(engines)]
+    for _ in range(3):
+        for s in st:
+            s.engine.local_maxabs(s.maxabs)
+        m = torch.stack([s.maxabs for s in st]).max(dim=0).values
+        for s in st:
+            s.maxabs.copy_(m)
+            s.engine.export_run(s.maxabs, s.mine)
+        full = torch.cat([s.mine for s in st], dim=0)
+        for s in st:
+            s.engine.step_runs(full, dt)
+    for e in engines:
+        ids, p, _ = e.owned_state()
+        assert np.array_equal(p, ref_p[ids])
+    assert engines[0].sim.tree_stats()["num_nodes"] == single.tree_stats()["num_nodes"]
+
+
 def test_record_writes_reference_format_and_resumes(gpu, tmp_path, oracle):
     from tools import record as rec
     from tools.presets import generate_distribution, get_preset_config
