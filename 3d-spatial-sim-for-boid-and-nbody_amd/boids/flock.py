@@ -7,6 +7,8 @@ physics (reference :627-678) in bdmi_step.  ``draw`` (OpenGL, :730) is out of sc
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 
 import nbmi_native as _nat
@@ -68,6 +70,10 @@ class Flock:
         self.num_cells = self.grid_dim ** 3
         self.grid_offset = float(self.bounds + self.cell_size)
         self.fog_end = float(config.CAMERA["far_clip"])
+        self.fov_margin = 1.15
+        self.cone_length = np.float32(B["size"])          # reference :466-467
+        self.cone_radius = np.float32(B["size"] * 0.35)
+        self.verts_per_boid = 6
         if seed is not None:  # the reference is unseeded; extra kwarg
             np.random.seed(seed)
         pos, vel, col = generate_initial_state(num_boids, self.bounds, self.max_speed)
@@ -149,8 +155,41 @@ class Flock:
                    "bdmi_get_timers")
         return dict(sort_ms=ms[0], table_ms=ms[1], sweep_ms=ms[2], steps=int(cnt.value))
 
+    # ---- render-side reduction (reference :680-728) on the device -----------------------------
+    def visible_vertices(self, cam_pos=None, cam_forward=None, cam_right=None, cam_up=None, fov=None, aspect=None):
+        """What draw() (reference :730-756) hands to its VBOs: (vertices, vert_colors) float32,
+        6 rows per visible boid in ascending boid order; sets _visible_count.  Frustum test
+        (compute_visibility_numba), compaction and cone building (build_vertices_numba) run on
+        the GPU, only the visible part is copied back."""
+        n = self.num_boids
+        if cam_pos is None:  # reference: everything visible
+            cam = np.array([0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0], dtype=np.float64)
+            cam[0:3] = (0.0, 0.0, -1e300)
+            tan_h = tan_v = float("inf")
+            fog = float("inf")
+        else:
+            fov_rad = math.radians(fov) if fov else math.radians(75)
+            aspect = aspect if aspect else (16 / 9)
+            half_fov_v = (fov_rad / 2) * self.fov_margin
+            half_fov_h = math.atan(math.tan(half_fov_v) * aspect)
+            tan_h, tan_v, fog = math.tan(half_fov_h), math.tan(half_fov_v), self.fog_end
+            cam = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(3) for a in
+                                                       (cam_pos, cam_forward, cam_right, cam_up)]))
+        if getattr(self, "_vertices", None) is None:
+            self._vertices = np.zeros((n * 6, 3), dtype=np.float32)
+            self._vert_colors = np.zeros((n * 6, 3), dtype=np.float32)
+        cnt = C.c_int64(0)
+        _nat.check(self._lib.bdmi_visible_vertices(self._h, _nat.ptr(cam), tan_h, tan_v, fog, float(self.cone_length),
+                                                   float(self.cone_radius), _nat.ptr(self._vertices),
+                                                   _nat.ptr(self._vert_colors), n, C.addressof(cnt)),
+                   "bdmi_visible_vertices")
+        self._visible_count = int(cnt.value)
+        k = self._visible_count * self.verts_per_boid
+        return self._vertices[:k], self._vert_colors[:k]
+
     def draw(self, *args, **kwargs):
-        raise NotImplementedError("rendering (reference boids/flock.py:730) is out of scope of this build")
+        raise NotImplementedError("OpenGL rendering (reference boids/flock.py:730) is out of scope of this build; "
+                                  "visible_vertices() returns what draw() would upload")
 
     def close(self):
         if getattr(self, "_h", None):

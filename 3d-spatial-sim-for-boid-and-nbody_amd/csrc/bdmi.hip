@@ -20,6 +20,7 @@
 
 #include "../../include/bdmi.h"
 #include "common.h"
+#include "visible.h"
 
 namespace {
 
@@ -287,6 +288,10 @@ struct bdmi_flock {
     void *tmp_sort = nullptr;
     size_t tmp_sort_bytes = 0;
     double *stage = nullptr;  // 12 N doubles
+    // render-side reduction scratch (bdmi_visible_vertices), allocated on first use
+    uint8_t *vis_flag = nullptr;
+    uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
+    float *vis_verts = nullptr, *vis_cols = nullptr;  // 18 floats per boid each
     bool timers = false;
     hipEvent_t ev[4] = {};
     double ms[3] = {0, 0, 0};
@@ -576,6 +581,94 @@ int bdmi_get_timers(bdmi_flock *f, double *ms3, int64_t *count, int reset) {
     if (ms3) memcpy(ms3, f->ms, sizeof(f->ms));
     if (count) *count = f->timed;
     if (reset) { memset(f->ms, 0, sizeof(f->ms)); f->timed = 0; }
+    return 0;
+}
+
+namespace {
+// build_vertices_numba (flock.py:351-447): two triangles (tip/right/left, tip/up/down) per boid,
+// float64 arithmetic in the reference's order, one rounding to float32 on store.
+struct EmitCones {
+    Boids a;
+    double cone_length, cone_radius;
+    float *verts, *cols;
+    __device__ void operator()(int64_t k, int64_t, uint32_t slot) const {
+        const double wux = 0.0, wuy = 1.0, wuz = 0.0, wrx = 1.0, wry = 0.0, wrz = 0.0;
+        const double px = a.px[slot], py = a.py[slot], pz = a.pz[slot];
+        const double vx = a.vx[slot], vy = a.vy[slot], vz = a.vz[slot];
+        double speed = sqrt(vx * vx + vy * vy + vz * vz);
+        if (speed < 0.0001) speed = 0.0001;
+        const double fx = vx / speed, fy = vy / speed, fz = vz / speed;
+        double rx = fy * wuz - fz * wuy;
+        double ry = fz * wux - fx * wuz;
+        double rz = fx * wuy - fy * wux;
+        double r_len = sqrt(rx * rx + ry * ry + rz * rz);
+        if (r_len < 0.1) {
+            rx = fy * wrz - fz * wry;
+            ry = fz * wrx - fx * wrz;
+            rz = fx * wry - fy * wrx;
+            r_len = sqrt(rx * rx + ry * ry + rz * rz);
+        }
+        if (r_len > 0.0001) { rx /= r_len; ry /= r_len; rz /= r_len; }
+        const double ux = ry * fz - rz * fy;
+        const double uy = rz * fx - rx * fz;
+        const double uz = rx * fy - ry * fx;
+        const double r = cone_radius;
+        const float tip[3] = {(float)(px + fx * cone_length), (float)(py + fy * cone_length), (float)(pz + fz * cone_length)};
+        float *o = verts + 18 * k;
+        o[0] = tip[0]; o[1] = tip[1]; o[2] = tip[2];
+        o[3] = (float)(px + rx * r); o[4] = (float)(py + ry * r); o[5] = (float)(pz + rz * r);
+        o[6] = (float)(px - rx * r); o[7] = (float)(py - ry * r); o[8] = (float)(pz - rz * r);
+        o[9] = tip[0]; o[10] = tip[1]; o[11] = tip[2];
+        o[12] = (float)(px + ux * r); o[13] = (float)(py + uy * r); o[14] = (float)(pz + uz * r);
+        o[15] = (float)(px - ux * r); o[16] = (float)(py - uy * r); o[17] = (float)(pz - uz * r);
+        const float cr = (float)a.cr[slot], cg = (float)a.cg[slot], cb = (float)a.cb[slot];
+        float *c = cols + 18 * k;
+#pragma unroll
+        for (int v = 0; v < 6; v++) { c[3 * v] = cr; c[3 * v + 1] = cg; c[3 * v + 2] = cb; }
+    }
+};
+}  // namespace
+
+int bdmi_visible_vertices(bdmi_flock *f, const double *cam12, double tan_h, double tan_v, double fog_end,
+                          double cone_length, double cone_radius, float *out_vertices, float *out_colors,
+                          int64_t capacity_boids, int64_t *count) {
+    if (int rc = check(f)) return rc;
+    if (!cam12 || !count || capacity_boids < 0 || (capacity_boids > 0 && (!out_vertices || !out_colors))) {
+        nbmi::set_error("bdmi_visible_vertices: null argument");
+        return -1;
+    }
+    const int64_t n = f->n;
+    *count = 0;
+    if (n == 0) return 0;
+    const int64_t ntiles = vis::tiles_for(n);
+    if (!f->vis_flag) {
+        if (dev_alloc(f, &f->vis_flag, vis::flag_bytes(n)) || dev_alloc(f, &f->vis_slot, (size_t)ntiles * vis::kTile) ||
+            dev_alloc(f, &f->vis_tiles, ntiles + 1) || dev_alloc(f, &f->vis_verts, (size_t)n * 18) ||
+            dev_alloc(f, &f->vis_cols, (size_t)n * 18))
+            return -2;
+        NBMI_HIP_CHECK(hipMemsetAsync(f->vis_flag, 0, vis::flag_bytes(n), f->stream));
+    }
+    vis::Camera c;
+    for (int k = 0; k < 3; k++) { c.p[k] = cam12[k]; c.f[k] = cam12[3 + k]; c.r[k] = cam12[6 + k]; c.u[k] = cam12[9 + k]; }
+    c.tan_h = tan_h; c.tan_v = tan_v; c.z_near = 0.5; c.z_far = fog_end; c.margin = 1.0;
+    const Boids &a = f->A;
+    hipStream_t st = f->stream;
+    vis::k_mark<<<nblocks(n), kBlock, 0, st>>>(a.px, a.py, a.pz, a.id, n, c, f->vis_flag, f->vis_slot);
+    vis::k_count<<<(int)ntiles, vis::kBlock, 0, st>>>(f->vis_flag, n, f->vis_tiles);
+    vis::k_scan_tiles<<<1, vis::kBlock, 0, st>>>(f->vis_tiles, ntiles);
+    EmitCones e{a, cone_length, cone_radius, f->vis_verts, f->vis_cols};
+    vis::k_emit<<<(int)ntiles, vis::kBlock, 0, st>>>(f->vis_flag, f->vis_slot, f->vis_tiles, n, n, e);
+    NBMI_HIP_CHECK(hipGetLastError());
+    uint32_t total = 0;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&total, f->vis_tiles + ntiles, 4, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    *count = total;
+    const int64_t rows = (int64_t)total < capacity_boids ? (int64_t)total : capacity_boids;
+    if (rows > 0) {
+        NBMI_HIP_CHECK(hipMemcpyAsync(out_vertices, f->vis_verts, (size_t)rows * 72, hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipMemcpyAsync(out_colors, f->vis_cols, (size_t)rows * 72, hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -35,6 +35,7 @@
 
 #include "../../include/nbmi.h"
 #include "common.h"
+#include "visible.h"
 
 namespace nbmi {
 static thread_local char g_err[512] = "";
@@ -959,6 +960,9 @@ struct nbmi_sim {
     uint64_t *t_hi = nullptr, *t_lo = nullptr;
     float4 *t_posm = nullptr;
     int world = 0;  // > 0: run exchange enabled
+    // render-side reduction scratch (nbmi_visible_points), allocated on first use
+    uint8_t *vis_flag = nullptr;
+    uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     // timers
     bool timers = false;
@@ -1614,6 +1618,64 @@ int nbmi_exchange_step(nbmi_sim *s, const void *dev_runs, int world, int64_t run
         if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
     s->curbuf ^= 1;
     s->tree_valid = false;
+    return 0;
+}
+
+namespace {
+struct EmitPoints {
+    const double *x, *y, *z;
+    const float *colors;  // (N,3), original order
+    float *out_pos, *out_col;
+    __device__ void operator()(int64_t k, int64_t i, uint32_t slot) const {
+        out_pos[3 * k] = (float)x[slot];
+        out_pos[3 * k + 1] = (float)y[slot];
+        out_pos[3 * k + 2] = (float)z[slot];
+        out_col[3 * k] = colors[3 * i];
+        out_col[3 * k + 1] = colors[3 * i + 1];
+        out_col[3 * k + 2] = colors[3 * i + 2];
+    }
+};
+}  // namespace
+
+int nbmi_visible_points(nbmi_sim *s, const double *cam12, double tan_h, double tan_v, double far_dist, float *out_pos,
+                        float *out_col, int64_t capacity, int64_t *count) {
+    if (int rc = check_handle(s)) return rc;
+    if (!cam12 || !count || capacity < 0 || (capacity > 0 && (!out_pos || !out_col))) {
+        nbmi::set_error("nbmi_visible_points: null argument");
+        return NBMI_ERR_ARG;
+    }
+    const int64_t n = s->n;
+    *count = 0;
+    if (n == 0) return 0;
+    const int64_t ntiles = vis::tiles_for(n);
+    if (!s->vis_flag) {
+        if (dev_alloc(s, &s->vis_flag, vis::flag_bytes(n)) || dev_alloc(s, &s->vis_slot, (size_t)ntiles * vis::kTile) ||
+            dev_alloc(s, &s->vis_tiles, ntiles + 1))
+            return NBMI_ERR_HIP;
+        NBMI_HIP_CHECK(hipMemsetAsync(s->vis_flag, 0, vis::flag_bytes(n), s->stream));
+    }
+    vis::Camera c;
+    for (int k = 0; k < 3; k++) { c.p[k] = cam12[k]; c.f[k] = cam12[3 + k]; c.r[k] = cam12[6 + k]; c.u[k] = cam12[9 + k]; }
+    c.tan_h = tan_h; c.tan_v = tan_v; c.z_near = 0.1; c.z_far = far_dist; c.margin = 1.2;
+    Bodies cur = s->buf[s->curbuf];
+    hipStream_t st = s->stream;
+    float *d_pos = (float *)s->stage, *d_col = d_pos + 3 * n;  // stage holds 7 N doubles
+    vis::k_mark<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, cur.id, n, c, s->vis_flag, s->vis_slot);
+    vis::k_count<<<(int)ntiles, vis::kBlock, 0, st>>>(s->vis_flag, n, s->vis_tiles);
+    vis::k_scan_tiles<<<1, vis::kBlock, 0, st>>>(s->vis_tiles, ntiles);
+    EmitPoints e{cur.x, cur.y, cur.z, s->colors, d_pos, d_col};
+    vis::k_emit<<<(int)ntiles, vis::kBlock, 0, st>>>(s->vis_flag, s->vis_slot, s->vis_tiles, n, n, e);
+    NBMI_HIP_CHECK(hipGetLastError());
+    uint32_t total = 0;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&total, s->vis_tiles + ntiles, 4, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    *count = total;
+    const int64_t rows = (int64_t)total < capacity ? (int64_t)total : capacity;
+    if (rows > 0) {
+        NBMI_HIP_CHECK(hipMemcpyAsync(out_pos, d_pos, (size_t)rows * 12, hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipMemcpyAsync(out_col, d_col, (size_t)rows * 12, hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    }
     return 0;
 }
 

@@ -150,6 +150,22 @@ class _HIPSimulation:
         _nat.check(self._lib.nbmi_get_accelerations_f64(self._h, _nat.ptr(out)), "nbmi_get_accelerations_f64")
         return out
 
+    def visible_points(self, cam_pos, cam_forward, cam_right, cam_up, tan_h, tan_v, far_dist):
+        """Frustum culling + compaction on the device (reference compute_visibility_points,
+        nbody/simulation.py:403-434, and the gather of draw(), :927-928): returns
+        (positions[mask] float32, colors[mask] float32) in body order - only these rows leave the GPU."""
+        cam = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(3) for a in
+                                                   (cam_pos, cam_forward, cam_right, cam_up)]))
+        cnt = C.c_int64(0)
+        if not hasattr(self, "_vis_buf") or self._vis_buf[0].shape[0] != self.n:
+            self._vis_buf = (np.empty((self.n, 3), dtype=np.float32), np.empty((self.n, 3), dtype=np.float32))
+        p, c = self._vis_buf
+        _nat.check(self._lib.nbmi_visible_points(self._h, _nat.ptr(cam), float(tan_h), float(tan_v), float(far_dist),
+                                                 _nat.ptr(p), _nat.ptr(c), self.n, C.addressof(cnt)),
+                   "nbmi_visible_points")
+        k = int(cnt.value)
+        return p[:k], c[:k]
+
     def enable_timers(self, on=True):
         _nat.check(self._lib.nbmi_enable_timers(self._h, 1 if on else 0), "nbmi_enable_timers")
 

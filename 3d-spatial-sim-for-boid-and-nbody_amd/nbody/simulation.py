@@ -3,6 +3,8 @@ backend.  Same constructor, public attributes and ``update(dt)``; all physics ru
 through nbody.gpu_backend (there is no CPU Barnes-Hut in this package, so a missing HIP device
 is an error, not a fallback).  ``draw`` (OpenGL, reference :905) is out of scope.
 """
+import math
+
 import numpy as np
 
 from config import nbody as config
@@ -182,5 +184,25 @@ class NBodySimulation:
         self.velocities = self._gpu_sim.get_velocities()
         return self.velocities
 
+    def _compute_visibility(self, cam_pos, cam_forward, cam_right, cam_up, fov_v, aspect):
+        """Reference :880-903, on the device: sets _visible_count and keeps the compacted float32
+        positions / colours a viewer would upload (`visible_pos`, `visible_colors`)."""
+        half_fov_v = fov_v / 2
+        half_fov_h = math.atan(math.tan(half_fov_v) * aspect)
+        self.visible_pos, self.visible_colors = self._gpu_sim.visible_points(
+            cam_pos, cam_forward, cam_right, cam_up, math.tan(half_fov_h), math.tan(half_fov_v), self.fog_end)
+        self._visible_count = len(self.visible_pos)
+
+    def visible_arrays(self, cam_pos=None, cam_forward=None, cam_right=None, cam_up=None, fov=None, aspect=None):
+        """The two arrays draw() (reference :905-928) hands to its VBOs: (positions[mask] float32,
+        colors[mask]); everything is visible without a camera."""
+        if cam_pos is None:
+            self._visible_count = self.num_bodies
+            return self.positions.astype(np.float32), self.colors
+        fov_rad = math.radians(fov) if fov else math.radians(75)
+        self._compute_visibility(cam_pos, cam_forward, cam_right, cam_up, fov_rad, aspect if aspect else (16 / 9))
+        return self.visible_pos, self.visible_colors
+
     def draw(self, *args, **kwargs):
-        raise NotImplementedError("rendering (reference nbody/simulation.py:905) is out of scope of this build")
+        raise NotImplementedError("OpenGL rendering (reference nbody/simulation.py:905) is out of scope of this "
+                                  "build; visible_arrays() returns what draw() would upload")

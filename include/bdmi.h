@@ -55,6 +55,18 @@ int bdmi_grid_info(bdmi_flock *f, int32_t *grid_dim, int64_t *num_cells, int64_t
 int bdmi_enable_timers(bdmi_flock *f, int enable);
 int bdmi_get_timers(bdmi_flock *f, double *ms3, int64_t *count, int reset);
 
+
+/* ---- render-side reduction ------------------------------------------ */
+/* Flock._compute_visibility + _build_vertices on the device (flock.py:680-728): frustum test of
+ * compute_visibility_numba (:311-348; z < 0.5 or z > fog_end hidden), np.where order (ascending
+ * boid index), then build_vertices_numba (:351-447): 6 float32 vertices + 6 float32 colours per
+ * visible boid.  cam12 = {cam_pos, cam_forward, cam_right, cam_up}; tan_h / tan_v as the caller
+ * derives them from (fov, aspect, fov_margin).  *count = visible boids; at most capacity_boids of
+ * them are copied out ((count*6, 3) rows each).  Only the visible part crosses PCIe. */
+int bdmi_visible_vertices(bdmi_flock *f, const double *cam12, double tan_h, double tan_v, double fog_end,
+                          double cone_length, double cone_radius, float *out_vertices, float *out_colors,
+                          int64_t capacity_boids, int64_t *count);
+
 #ifdef __cplusplus
 }
 #endif

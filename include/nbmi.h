@@ -137,6 +137,16 @@ int nbmi_exchange_enable(nbmi_sim *sim, int64_t n_total, int world, int64_t run_
 int nbmi_exchange_maxabs(nbmi_sim *sim, void *dev_maxabs);
 int nbmi_exchange_export(nbmi_sim *sim, const void *dev_maxabs, void *dev_run, int64_t run_rows);
 int nbmi_exchange_step(nbmi_sim *sim, const void *dev_runs, int world, int64_t run_rows, double dt);
+
+/* Render-side reduction: NBodySimulation._compute_visibility + the gather of
+ * draw() on the device (nbody/simulation.py:880-903, 927-928).  Frustum test of
+ * compute_visibility_points (:403-434; z < 0.1 or z > far_dist hidden, 20 % margin) on the float64
+ * device positions, then positions[mask].astype(float32) and colors[mask] (colours of the last
+ * nbmi_compute_colors) in the caller's body order.  cam12 = {cam_pos, cam_forward, cam_right,
+ * cam_up}.  *count = visible bodies; at most `capacity` rows are copied out.  Only the visible
+ * part crosses PCIe. */
+int nbmi_visible_points(nbmi_sim *sim, const double *cam12, double tan_h, double tan_v, double far_dist,
+                        float *out_positions_xyz, float *out_colors_rgb, int64_t capacity, int64_t *count);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 

@@ -241,3 +241,76 @@ void bdref_step(double *pos, double *vel, double *col, int64_t n, const double *
     bdref_update_physics(pos, vel, col, sepf, alif, cohf, avg, bounds, margin, max_force * wall_weight,
                          max_speed, blend, dt, n);
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Render-side reductions.
+ * bdref_visibility      flock.py:311-348  compute_visibility_numba (z < 0.5 or z > fog_end hidden,
+ *                                         no margin factor)
+ * bdref_build_vertices  flock.py:351-447  build_vertices_numba: 6 float32 vertices (two triangles:
+ *                                         tip/right/left, tip/up/down) + 6 colours per visible boid
+ * cam = {pos[3], forward[3], right[3], up[3]}.
+ * ------------------------------------------------------------------------------------------- */
+void bdref_visibility(const double *pos, const double *cam, double tan_h, double tan_v, double fog_end,
+                      uint8_t *visible_mask, int64_t n) {
+    const double *cp = cam, *cf = cam + 3, *cr = cam + 6, *cu = cam + 9;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const double dx = pos[3 * i] - cp[0], dy = pos[3 * i + 1] - cp[1], dz = pos[3 * i + 2] - cp[2];
+        const double z = dx * cf[0] + dy * cf[1] + dz * cf[2];
+        if (z < 0.5 || z > fog_end) {
+            visible_mask[i] = 0;
+            continue;
+        }
+        const double x = dx * cr[0] + dy * cr[1] + dz * cr[2];
+        const double y = dx * cu[0] + dy * cu[1] + dz * cu[2];
+        const double half_width = z * tan_h;
+        const double half_height = z * tan_v;
+        visible_mask[i] = (fabs(x) < half_width && fabs(y) < half_height) ? 1 : 0;
+    }
+}
+
+void bdref_build_vertices(const double *pos, const double *vel, const double *col, const int32_t *visible_indices,
+                          float *vertices, float *vert_colors, double cone_length, double cone_radius,
+                          int64_t num_visible) {
+    const double wux = 0.0, wuy = 1.0, wuz = 0.0;  /* world up */
+    const double wrx = 1.0, wry = 0.0, wrz = 0.0;  /* world right */
+#pragma omp parallel for schedule(static)
+    for (int64_t idx = 0; idx < num_visible; idx++) {
+        const int64_t i = visible_indices[idx];
+        const double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+        const double vx = vel[3 * i], vy = vel[3 * i + 1], vz = vel[3 * i + 2];
+        double speed = sqrt(vx * vx + vy * vy + vz * vz);
+        if (speed < 0.0001) speed = 0.0001;
+        const double fx = vx / speed, fy = vy / speed, fz = vz / speed;
+        double rx = fy * wuz - fz * wuy;
+        double ry = fz * wux - fx * wuz;
+        double rz = fx * wuy - fy * wux;
+        double r_len = sqrt(rx * rx + ry * ry + rz * rz);
+        if (r_len < 0.1) {
+            rx = fy * wrz - fz * wry;
+            ry = fz * wrx - fx * wrz;
+            rz = fx * wry - fy * wrx;
+            r_len = sqrt(rx * rx + ry * ry + rz * rz);
+        }
+        if (r_len > 0.0001) {
+            rx /= r_len; ry /= r_len; rz /= r_len;
+        }
+        const double ux = ry * fz - rz * fy;
+        const double uy = rz * fx - rx * fz;
+        const double uz = rx * fy - ry * fx;
+        const double r = cone_radius;
+        const double v[6][3] = {
+            {px + fx * cone_length, py + fy * cone_length, pz + fz * cone_length},
+            {px + rx * r, py + ry * r, pz + rz * r},
+            {px - rx * r, py - ry * r, pz - rz * r},
+            {px + fx * cone_length, py + fy * cone_length, pz + fz * cone_length},
+            {px + ux * r, py + uy * r, pz + uz * r},
+            {px - ux * r, py - uy * r, pz - uz * r},
+        };
+        float *o = vertices + 18 * idx, *c = vert_colors + 18 * idx;
+        for (int k = 0; k < 6; k++) {
+            o[3 * k] = (float)v[k][0]; o[3 * k + 1] = (float)v[k][1]; o[3 * k + 2] = (float)v[k][2];
+            c[3 * k] = (float)col[3 * i]; c[3 * k + 1] = (float)col[3 * i + 1]; c[3 * k + 2] = (float)col[3 * i + 2];
+        }
+    }
+}

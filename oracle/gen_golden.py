@@ -19,6 +19,8 @@ Functions exercised (reference file:line):
   boids/flock.py:454       Flock (+ the five @njit kernels it drives)
   tools/presets.py:91      generate_distribution (galaxy / collision / cluster)
   tools/record.py:88       save_frame
+  nbody/simulation.py:403  compute_visibility_points
+  boids/flock.py:311,:351  compute_visibility_numba, build_vertices_numba
 
 Usage:  python oracle/gen_golden.py [--only NAME ...] [--procs 8]
 """
@@ -434,7 +436,68 @@ def job_frame(args):
          dec_p1=(p0 + dpos.astype(np.float32) / 1000.0), dec_c1=(c0 + dcol.astype(np.float32) / 1000.0))
 
 
-JOBS = dict(ic=job_ic, tree=job_tree, edge=job_edge, colors=job_colors, direct=job_direct, boids=job_boids,
+def _cameras():
+    """Four camera poses: outside looking at the origin, inside, grazing, narrow field."""
+    cams = []
+    for eye, target, fov_deg, aspect in [((0.0, 120.0, 600.0), (0.0, 0.0, 0.0), 75.0, 16 / 9),
+                                         ((15.0, 3.0, -20.0), (100.0, 10.0, 40.0), 75.0, 16 / 9),
+                                         ((-300.0, 2.0, 0.0), (300.0, 0.0, 5.0), 60.0, 4 / 3),
+                                         ((40.0, 35.0, 40.0), (0.0, 0.0, 0.0), 20.0, 1.0)]:
+        eye, target = np.array(eye), np.array(target)
+        f = target - eye
+        f /= np.linalg.norm(f)
+        r = np.cross(f, np.array([0.0, 1.0, 0.0]))
+        r /= np.linalg.norm(r)
+        u = np.cross(r, f)
+        cams.append((eye, f, r, u, np.radians(fov_deg), aspect))
+    return cams
+
+
+def job_visibility(args):
+    """Render-side reductions: compute_visibility_points (nbody/simulation.py:403) and
+    compute_visibility_numba + build_vertices_numba (boids/flock.py:311, :351), called with the
+    tangents NBodySimulation._compute_visibility (:880-903) / Flock._compute_visibility (:680-709)
+    derive from (fov, aspect)."""
+    import math
+    import config.boids as bcfg
+    import boids.flock as refflock
+    p, v, m = gen_ic("galaxy", 2048, 500.0, 0.15)
+    out = dict(pos=p)
+    for k, (eye, f, r, u, fov, aspect) in enumerate(_cameras()):
+        half_v = fov / 2
+        half_h = math.atan(math.tan(half_v) * aspect)
+        mask = np.zeros(len(p), dtype=np.bool_)
+        refsim.compute_visibility_points(p, eye, f, r, u, math.tan(half_h), math.tan(half_v), 5000.0, mask, len(p))
+        out.update({f"cam_{k}": np.concatenate([eye, f, r, u]), f"tan_{k}": np.array([math.tan(half_h), math.tan(half_v)]),
+                    f"mask_{k}": mask})
+    out["far"] = 5000.0
+    save("visibility_nbody", **out)
+
+    saved = dict(bcfg.BOIDS)
+    bcfg.BOIDS["bounds"] = 40.0
+    try:
+        np.random.seed(42)
+        fl = refflock.Flock(4096)
+    finally:
+        bcfg.BOIDS.clear()
+        bcfg.BOIDS.update(saved)
+    fl.velocities[5] = 0.0           # speed floor branch
+    fl.velocities[6] = (0.0, 7.0, 0.0)   # forward parallel to world-up: world-right branch
+    out = dict(pos=fl.positions.copy(), vel=fl.velocities.copy(), col=fl.colors.copy(),
+               cone_length=float(fl.cone_length), cone_radius=float(fl.cone_radius), fog_end=float(fl.fog_end))
+    for k, (eye, f, r, u, fov, aspect) in enumerate(_cameras()):
+        eye = eye * 0.1  # the flock lives in +-40
+        fl._compute_visibility(eye, f, r, u, fov, aspect)
+        nv = fl._build_vertices()
+        half_v = (fov / 2) * fl.fov_margin
+        half_h = math.atan(math.tan(half_v) * aspect)
+        out.update({f"cam_{k}": np.concatenate([eye, f, r, u]), f"tan_{k}": np.array([math.tan(half_h), math.tan(half_v)]),
+                    f"mask_{k}": fl._visible_mask.copy(), f"vertices_{k}": fl._vertices[:nv].copy(),
+                    f"vert_colors_{k}": fl._vert_colors[:nv].copy()})
+    save("visibility_boids", **out)
+
+
+JOBS = dict(visibility=job_visibility, ic=job_ic, tree=job_tree, edge=job_edge, colors=job_colors, direct=job_direct, boids=job_boids,
             frame=job_frame, traj2048=job_traj2048, tree10k=job_tree10k, tree100k=job_tree100k,
             traj10k=job_traj10k)
 

@@ -467,3 +467,27 @@ void nbref_group_walk_stats(const double *pos, const int64_t *order, int64_t n, 
     (void)body_idx;
     out[0] = sum_union; out[1] = sum_body; out[2] = ngroups; out[3] = max_union;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Render-side reduction: compute_visibility_points, nbody/simulation.py:403-434.
+ * z < 0.1 or z > far_dist -> hidden; else |x| < z*tan_h*1.2 and |y| < z*tan_v*1.2.
+ * cam = {pos[3], forward[3], right[3], up[3]}.
+ * ------------------------------------------------------------------------------------------- */
+void nbref_visibility_points(const double *pos, const double *cam, double tan_h, double tan_v, double far_dist,
+                             uint8_t *visible_mask, int64_t n) {
+    const double *cp = cam, *cf = cam + 3, *cr = cam + 6, *cu = cam + 9;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        const double dx = pos[3 * i] - cp[0], dy = pos[3 * i + 1] - cp[1], dz = pos[3 * i + 2] - cp[2];
+        const double z = dx * cf[0] + dy * cf[1] + dz * cf[2];
+        if (z < 0.1 || z > far_dist) {
+            visible_mask[i] = 0;
+            continue;
+        }
+        const double x = dx * cr[0] + dy * cr[1] + dz * cr[2];
+        const double y = dx * cu[0] + dy * cu[1] + dz * cu[2];
+        const double half_width = z * tan_h * 1.2;
+        const double half_height = z * tan_v * 1.2;
+        visible_mask[i] = (fabs(x) < half_width && fabs(y) < half_height) ? 1 : 0;
+    }
+}

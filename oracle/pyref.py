@@ -70,6 +70,12 @@ def _bind(lib):
     lib.nbref_group_walk_stats.restype = None
     lib.nbref_group_walk_stats.argtypes = [_f64p, _i64p, _i64, C.c_int, _f64p, _f64p, _i32p, _i32p, _u8p, _dbl,
                                            _dbl, _i64p]
+    lib.nbref_visibility_points.restype = None
+    lib.nbref_visibility_points.argtypes = [_f64p, _f64p, _dbl, _dbl, _dbl, _u8p, _i64]
+    lib.bdref_visibility.restype = None
+    lib.bdref_visibility.argtypes = [_f64p, _f64p, _dbl, _dbl, _dbl, _u8p, _i64]
+    lib.bdref_build_vertices.restype = None
+    lib.bdref_build_vertices.argtypes = [_f64p, _f64p, _f64p, _i32p, _f32p, _f32p, _dbl, _dbl, _i64]
     lib.bdref_assign_cells.restype = None
     lib.bdref_assign_cells.argtypes = [_f64p, _i32p, _dbl, C.c_int, _dbl, _i64]
     lib.bdref_build_cell_lists.restype = None
@@ -157,6 +163,40 @@ def compute_colors_by_velocity(vel, max_speed, L=None):
     col = np.zeros((len(vel), 3), dtype=np.float32)
     (L or lib()).nbref_colors(np.ascontiguousarray(vel, np.float64), col, len(vel), max_speed)
     return col
+
+
+def _cam(cam_pos, cam_forward, cam_right, cam_up):
+    return np.ascontiguousarray(np.concatenate([cam_pos, cam_forward, cam_right, cam_up]), dtype=np.float64)
+
+
+def compute_visibility_points(pos, cam_pos, cam_forward, cam_right, cam_up, tan_h, tan_v, far_dist, L=None):
+    """nbody/simulation.py:403-434; returns the bool mask."""
+    mask = np.zeros(len(pos), dtype=np.uint8)
+    (L or lib()).nbref_visibility_points(np.ascontiguousarray(pos, np.float64),
+                                         _cam(cam_pos, cam_forward, cam_right, cam_up), tan_h, tan_v, far_dist,
+                                         mask, len(pos))
+    return mask.astype(bool)
+
+
+def compute_visibility_boids(pos, cam_pos, cam_forward, cam_right, cam_up, tan_h, tan_v, fog_end, L=None):
+    """boids/flock.py:311-348 compute_visibility_numba; returns the bool mask."""
+    mask = np.zeros(len(pos), dtype=np.uint8)
+    (L or lib()).bdref_visibility(np.ascontiguousarray(pos, np.float64),
+                                  _cam(cam_pos, cam_forward, cam_right, cam_up), tan_h, tan_v, fog_end, mask,
+                                  len(pos))
+    return mask.astype(bool)
+
+
+def build_vertices(pos, vel, col, visible_indices, cone_length, cone_radius, L=None):
+    """boids/flock.py:351-447 build_vertices_numba; returns (vertices, vert_colors) float32 (6k,3)."""
+    k = len(visible_indices)
+    verts = np.zeros((6 * k, 3), dtype=np.float32)
+    vcols = np.zeros((6 * k, 3), dtype=np.float32)
+    (L or lib()).bdref_build_vertices(np.ascontiguousarray(pos, np.float64), np.ascontiguousarray(vel, np.float64),
+                                      np.ascontiguousarray(col, np.float64),
+                                      np.ascontiguousarray(visible_indices, np.int32), verts, vcols,
+                                      float(cone_length), float(cone_radius), k)
+    return verts, vcols
 
 
 def direct_forces(pos, masses, G, softening, L=None):

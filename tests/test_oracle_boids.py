@@ -48,3 +48,22 @@ def test_counting_sort_variant_close(oracle):
     b.step(float(g["dt"]))
     assert np.allclose(a.pos, b.pos, rtol=0, atol=1e-11)
     assert np.allclose(a.vel, b.vel, rtol=0, atol=1e-10)
+
+
+def test_visibility_and_cone_vertices_match_reference(oracle):
+    """compute_visibility_numba + build_vertices_numba (flock.py:311-447): masks exact; the float32
+    vertices exact too (float64 arithmetic in source order, one rounding on store)."""
+    g = golden("visibility_boids")
+    for k in range(4):
+        cam = g[f"cam_{k}"]
+        th, tv = g[f"tan_{k}"]
+        mask = oracle.compute_visibility_boids(g["pos"], cam[0:3], cam[3:6], cam[6:9], cam[9:12], float(th), float(tv),
+                                               float(g["fog_end"]))
+        assert np.array_equal(mask, g[f"mask_{k}"])
+        idx = np.where(mask)[0].astype(np.int32)
+        verts, vcols = oracle.build_vertices(g["pos"], g["vel"], g["col"], idx, float(g["cone_length"]),
+                                             float(g["cone_radius"]))
+        assert np.array_equal(verts, g[f"vertices_{k}"])
+        assert np.array_equal(vcols, g[f"vert_colors_{k}"])
+    # the degenerate boids (zero speed, velocity along world-up) are among the visible ones of pose 0
+    assert g["mask_0"][5] and g["mask_0"][6]

@@ -152,3 +152,16 @@ def test_node_cap_quirk(oracle):
     capped = oracle.build_octree(pos, m, b, nd, cap=200)
     attached = int(((nd.body[:200] >= 0) & (nd.leaf[:200] == 1)).sum())
     assert full > 500 and capped >= 200 and attached < 500
+
+
+def test_visibility_points_matches_reference(oracle):
+    """compute_visibility_points (simulation.py:403-434) on four camera poses: the mask the
+    reference function produced is reproduced exactly."""
+    g = golden("visibility_nbody")
+    for k in range(4):
+        cam = g[f"cam_{k}"]
+        th, tv = g[f"tan_{k}"]
+        mask = oracle.compute_visibility_points(g["pos"], cam[0:3], cam[3:6], cam[6:9], cam[9:12], float(th), float(tv),
+                                                float(g["far"]))
+        assert np.array_equal(mask, g[f"mask_{k}"])
+        assert 0 < mask.sum() <= len(mask)
