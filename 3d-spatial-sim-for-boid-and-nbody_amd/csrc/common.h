@@ -43,4 +43,29 @@ struct RunRec {
     uint64_t hi, lo;
     float x, y, z, gm;
 };
+
+// ---- device-side initial conditions (icgen.hip) ---------------------------------------------
+#define NBMI_IC_GALAXY 0
+#define NBMI_IC_COLLISION 1
+#define NBMI_IC_CLUSTER 2
+struct IcArrays {
+    double *x, *y, *z, *vx, *vy, *vz, *m;
+    int32_t *id;
+};
+int ic_generate(int distribution, int64_t n, double R, double G, uint64_t seed, IcArrays out, hipStream_t s);
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based generator, 4 x 32 bits per call.
+__host__ __device__ inline void philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
 }  // namespace nbmi

@@ -1196,7 +1196,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
     }
     // upload AoS host arrays through the staging buffer and split to SoA
     double *dpos = (double *)s->stage, *dvel = dpos + 3 * n, *dm = dvel + 3 * n;
-    if (n > 0) {
+    if (n > 0 && pos) {  // pos == NULL: the caller fills buf[0] on the device (nbmi_create_generated)
         NBMI_HIP_CHECK(hipMemcpyAsync(dpos, pos, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
         NBMI_HIP_CHECK(hipMemcpyAsync(dvel, vel, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
         NBMI_HIP_CHECK(hipMemcpyAsync(dm, mass, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -1248,6 +1248,59 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
         return nullptr;
     }
     return s;
+}
+
+nbmi_sim *nbmi_create_generated(int distribution, int64_t n, double spawn_radius, uint64_t seed, double G,
+                                double softening, double damping, double theta, int method, int device) {
+    nbmi::clear_error();
+    if (n < 0 || n > 30000000 || distribution < NBMI_IC_GALAXY || distribution > NBMI_IC_CLUSTER ||
+        (method != NBMI_METHOD_BARNES_HUT && method != NBMI_METHOD_DIRECT) || !(softening >= 0.0) || !(theta >= 0.0) ||
+        !(spawn_radius > 0.0)) {
+        nbmi::set_error("nbmi_create_generated: bad arguments (n=%lld, distribution=%d)", (long long)n, distribution);
+        return nullptr;
+    }
+    const int count = nbmi_device_count();
+    if (count <= 0 || device < 0 || device >= count) {
+        nbmi::set_error("nbmi_create_generated: no HIP device %d (have %d)", device, count);
+        return nullptr;
+    }
+    nbmi_sim *s = new nbmi_sim();
+    s->n = n; s->method = method; s->device = device;
+    s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
+    if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);
+    int rc = create_impl(s, nullptr, nullptr, nullptr);
+    if (rc == 0) {
+        Bodies &b = s->buf[0];
+        rc = nbmi::ic_generate(distribution, n, spawn_radius, G, seed, nbmi::IcArrays{b.x, b.y, b.z, b.vx, b.vy, b.vz, b.m, b.id},
+                               s->stream);
+    }
+    if (rc != 0) {
+        std::string keep = nbmi::get_error();
+        nbmi_destroy(s);
+        nbmi::set_error("%s", keep.c_str());
+        return nullptr;
+    }
+    return s;
+}
+
+void nbmi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    nbmi::philox4x32_10(counter, key, out);
+}
+
+int nbmi_get_masses_f64(nbmi_sim *s, double *out) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!out) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    Bodies cur = s->buf[s->curbuf];
+    // scatter to the caller's order through the 3-component un-permute (components 1, 2 unused)
+    k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(cur.m, cur.m, cur.m, cur.id, n, (double *)s->stage);
+    NBMI_HIP_CHECK(hipGetLastError());
+    std::vector<double> tmp((size_t)n * 3);
+    NBMI_HIP_CHECK(hipMemcpyAsync(tmp.data(), s->stage, (size_t)n * 24, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    for (int64_t i = 0; i < n; i++) out[i] = tmp[3 * i];
+    return 0;
 }
 
 int nbmi_step(nbmi_sim *s, double dt, int substeps) {

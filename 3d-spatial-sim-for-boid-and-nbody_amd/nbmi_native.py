@@ -21,6 +21,9 @@ PROTOTYPES = {
     "nbmi_device_count": (C.c_int, []),
     "nbmi_last_error": (C.c_char_p, []),
     "nbmi_create": (_vp, [_i64, _vp, _vp, _vp, _dbl, _dbl, _dbl, _dbl, C.c_int, C.c_int]),
+    "nbmi_create_generated": (_vp, [C.c_int, _i64, _dbl, C.c_uint64, _dbl, _dbl, _dbl, _dbl, C.c_int, C.c_int]),
+    "nbmi_philox4x32_10": (None, [_vp, _vp, _vp]),
+    "nbmi_get_masses_f64": (C.c_int, [_vp, _vp]),
     "nbmi_destroy": (None, [_vp]),
     "nbmi_step": (C.c_int, [_vp, _dbl, C.c_int]),
     "nbmi_compute_colors": (C.c_int, [_vp, _dbl]),

@@ -102,6 +102,35 @@ class _HIPSimulation:
         kind = "Barnes-Hut" if self._method == METHOD_BARNES_HUT else "direct N^2"
         print(f"[HIP] Initialized with {self.n:,} bodies ({kind}) on device {self.device}")
 
+    @classmethod
+    def generated(cls, distribution, n, spawn_radius, G, softening, damping, theta=0.5, seed=42, device=None):
+        """Same backend object, but the bodies are drawn ON THE DEVICE from the reference's
+        generate_distribution formulas (tools/presets.py:104-232, :350-397; `distribution` in
+        "galaxy" / "collision" / "cluster") with a Philox stream keyed by `seed`: statistical,
+        not bit, parity with the NumPy generator; no host arrays, no upload."""
+        kinds = {"galaxy": 0, "collision": 1, "cluster": 2}
+        if distribution not in kinds:
+            raise ValueError(f"device-side generator has {sorted(kinds)}, not {distribution!r}")
+        self = cls.__new__(cls)
+        lib = _nat.load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, _nat.device_count())
+        self.n = int(n)
+        self.G, self.softening, self.damping, self.theta = float(G), float(softening), float(damping), float(theta)
+        self.device = int(device)
+        self._lib = lib
+        self._h = lib.nbmi_create_generated(kinds[distribution], self.n, float(spawn_radius), int(seed) & (2 ** 64 - 1),
+                                            self.G, self.softening, self.damping, self.theta, cls._method, self.device)
+        if not self._h:
+            raise RuntimeError(f"nbmi_create_generated failed: {_nat.last_error()}")
+        print(f"[HIP] Generated {self.n:,} bodies ({distribution}, seed {seed}) on device {self.device}")
+        return self
+
+    def get_masses(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        _nat.check(self._lib.nbmi_get_masses_f64(self._h, _nat.ptr(out)), "nbmi_get_masses_f64")
+        return out
+
     # ---- reference protocol -------------------------------------------------------------
     def step(self, dt: float):
         _nat.check(self._lib.nbmi_step(self._h, float(dt), 1), "nbmi_step")

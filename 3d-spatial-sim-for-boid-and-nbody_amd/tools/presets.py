@@ -133,6 +133,17 @@ def generate_distribution(distribution: str, n: int, R: float, G: float) -> Tupl
     return positions, velocities, masses
 
 
+def generate_distribution_device(distribution: str, n: int, R: float, G: float, softening: float, damping: float = 1.0,
+                                 theta: float = 0.5, seed: int = 42, device=None):
+    """generate_distribution + backend construction in one step, on the GPU: returns a
+    HIPBarnesHutSimulation whose bodies were drawn on the device (nbmi_create_generated; Philox
+    stream, statistical parity with generate_distribution).  At 10 M bodies this replaces seconds of
+    NumPy and a 640 MB upload by a few milliseconds."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    return HIPBarnesHutSimulation.generated(distribution, n, R, G, softening, damping, theta=theta, seed=seed,
+                                            device=device)
+
+
 def _preset(name, desc, cat, n, theta, G, eps, R, dist, frames, dtf, sub, fps, est):
     return {"name": name, "description": desc, "category": cat, "num_bodies": n, "theta": theta, "G": G,
             "softening": eps, "damping": 1.0, "spawn_radius": R, "distribution": dist, "total_frames": frames,

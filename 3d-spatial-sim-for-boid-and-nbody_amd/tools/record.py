@@ -267,10 +267,12 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
                     masses = st["masses"].astype(np.float64) if "masses" in st.files else None
                 start_frame = state_frame + 1
                 say(f"[Record] Resuming from frame {start_frame}")
+    device_ic = bool(config.get("device_ic")) and positions is None
     if positions is None:
-        if seed is not None:
-            np.random.seed(seed)
-        positions, velocities, masses = _generate_initial_conditions(config)
+        if not device_ic:
+            if seed is not None:
+                np.random.seed(seed)
+            positions, velocities, masses = _generate_initial_conditions(config)
         save_metadata(rec_dir, config, time.time())
     n = config["num_bodies"]
     total_frames = config["total_frames"]
@@ -282,8 +284,14 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
     backend, info = get_backend()
     if backend != Backend.HIP:
         raise RuntimeError(f"[Record] no HIP backend ({info}); this build has no CPU fallback")
-    gpu_sim = create_gpu_simulation(positions, velocities, masses, config["G"], config["softening"],
-                                    config["damping"], theta=config.get("theta", 0.5), force_gpu=True)
+    if device_ic:  # extra config key: bodies drawn on the GPU (statistical parity with the presets' generator)
+        from tools.presets import generate_distribution_device
+        gpu_sim = generate_distribution_device(config.get("distribution", "galaxy"), n, config["spawn_radius"],
+                                               config["G"], config["softening"], config["damping"],
+                                               theta=config.get("theta", 0.5), seed=42 if seed is None else seed)
+    else:
+        gpu_sim = create_gpu_simulation(positions, velocities, masses, config["G"], config["softening"],
+                                        config["damping"], theta=config.get("theta", 0.5), force_gpu=True)
     if gpu_sim is None:
         raise RuntimeError("[Record] create_gpu_simulation returned None")
     say(f"[Record] GPU acceleration: {backend.value} - {info}")

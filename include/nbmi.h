@@ -49,6 +49,23 @@ nbmi_sim *nbmi_create(int64_t n, const double *positions_xyz, const double *velo
                       const double *masses, double G, double softening, double damping,
                       double theta, int method, int device);
 
+/* Constructor with DEVICE-SIDE initial conditions: the bodies are drawn on the
+ * GPU from generate_distribution's formulas (tools/presets.py:104-232 "galaxy" / "collision",
+ * :350-397 "cluster"; unit masses) with a counter-based Philox4x32-10 stream keyed by `seed`, so a
+ * 10 M-body start needs no host generator and no 640 MB upload.  Statistical, not bit, parity with
+ * the NumPy generator; the same (seed, n, radius, G) always gives the same bodies.  G is used both
+ * for the rotation curve / dispersions and for the simulation, as record() does
+ * (tools/record.py:747-758).  Body i of the getters is the i-th generated body. */
+#define NBMI_IC_GALAXY 0
+#define NBMI_IC_COLLISION 1
+#define NBMI_IC_CLUSTER 2
+nbmi_sim *nbmi_create_generated(int distribution, int64_t n, double spawn_radius, uint64_t seed, double G,
+                                double softening, double damping, double theta, int method, int device);
+/* The generator's random function, computed on the host (known-answer tests). */
+void nbmi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* Masses (N,) float64 in the caller's order (state checkpoints of generated systems). */
+int nbmi_get_masses_f64(nbmi_sim *sim, double *out);
+
 void nbmi_destroy(nbmi_sim *sim);
 
 /* step(dt): gpu_backend.py:368-386.  `substeps` consecutive steps of size dt are enqueued on

@@ -227,3 +227,37 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dp, fn)).read()
                 assert "pyref" not in text and "nbref" not in text and "bdref" not in text, os.path.join(dp, fn)
+
+
+def test_philox_known_answers():
+    """The generator behind the device-side ICs is Philox4x32-10 (Salmon et al. 2011).  Host entry
+    point of the same inline function the kernels call; vectors from the Random123 distribution's
+    known-answer file, plus an independent Python restatement on random inputs."""
+    import ctypes as C
+    import nbmi_native
+    lib = nbmi_native.load()
+
+    def dev(ctr, key):
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        lib.nbmi_philox4x32_10(c, k, o)
+        return list(o)
+
+    def ref(ctr, key):
+        c, k = list(ctr), list(key)
+        for _ in range(10):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+            k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+        return c
+
+    assert dev([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert dev([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert dev([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        ctr = [int(v) for v in rng.randint(0, 2 ** 32, 4, dtype=np.uint64)]
+        key = [int(v) for v in rng.randint(0, 2 ** 32, 2, dtype=np.uint64)]
+        assert dev(ctr, key) == ref(ctr, key)
