@@ -526,45 +526,59 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     return any_open ? nd.seq_off : nd.next_off;
 }
 
-// Hand-scheduled visit for the product kernel (eps > 0, no counters): 17 VALU + 5 scalar
-// instructions.  Scalar issue is the scarce resource on gfx950 (one slot per SIMD every ~4 cycles,
-// scripts/ubench/issue_rate.hip), so: one s_load_dwordx8 at an SGPR byte offset, s_andn2 leaves
-// "any lane opens" in SCC for the s_cselect that picks seq_off / next_off, `take` goes to VCC for
-// the two selects.  Node dwords land in s[36:43]: cx cy cz gm s2t next_off seq_off ref.
-#define NBMI_VISIT_ASM                                         \
-    "s_load_dwordx8 s[36:43], %[base], %[off]\n"               \
+// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 5 scalar
+// instructions per visit.  One s_load_dwordx8 at an SGPR byte offset.  The two compares are
+// v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those that TAKE the node,
+// so the force instructions and the `resume` update need no per-lane selects; s_andn2 of the two
+// masks leaves "some lane opens" in SCC for the s_cselect that picks seq_off / next_off; EXEC is
+// all-ones again before the next visit (every launched wave is full; lanes without a body carry
+// resume = ~0 and never take part).  The node record of the NEXT visit is requested as soon as its offset
+// is known - before the nine force instructions of the current visit are issued - into the other
+// of two SGPR banks (A = s[36:43], B = s[48:55]: cx cy cz gm s2t next_off seq_off ref), which
+// takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
+// asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
+// a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
+#define NBMI_VISIT(CX, CY, CZ, GM, S2T, NXT, SEQ, NEXTBANK)    \
+    "v_cmpx_ge_u32_e64 s[44:45], %[off], %[resume]\n"          \
     "s_waitcnt lgkmcnt(0)\n"                                   \
-    "v_cmp_ge_u32_e64 s[44:45], %[off], %[resume]\n"           \
-    "v_sub_f32_e32 %[dx], s36, %[px]\n"                        \
-    "v_sub_f32_e32 %[dy], s37, %[py]\n"                        \
-    "v_sub_f32_e32 %[dz], s38, %[pz]\n"                        \
+    "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
+    "v_sub_f32_e32 %[dy], " CY ", %[py]\n"                     \
+    "v_sub_f32_e32 %[dz], " CZ ", %[pz]\n"                     \
     "v_fma_f32 %[d2], %[dx], %[dx], %[eps2]\n"                 \
     "v_fmac_f32_e32 %[d2], %[dy], %[dy]\n"                     \
     "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
-    "v_cmp_lt_i32_e64 s[46:47], s40, %[d2]\n"                  \
+    "v_cmpx_lt_i32_e64 s[46:47], " S2T ", %[d2]\n"             \
+    "s_andn2_b64 s[56:57], s[44:45], s[46:47]\n"               \
+    "s_cselect_b32 %[off], " SEQ ", " NXT "\n"                 \
+    "s_load_dwordx8 " NEXTBANK ", %[base], %[off]\n"           \
     "v_rsq_f32_e32 %[inv], %[d2]\n"                            \
-    "s_and_b64 vcc, s[44:45], s[46:47]\n"                      \
-    "s_andn2_b64 s[44:45], s[44:45], s[46:47]\n"               \
-    "s_cselect_b32 %[off], s42, s41\n"                         \
-    "v_mul_f32_e32 %[f], s39, %[inv]\n"                        \
+    "v_mov_b32_e32 %[resume], " NXT "\n"                       \
+    "v_mul_f32_e32 %[f], " GM ", %[inv]\n"                     \
     "v_mul_f32_e32 %[t], %[inv], %[inv]\n"                     \
     "v_mul_f32_e32 %[f], %[f], %[t]\n"                         \
-    "v_mov_b32_e32 %[t], s41\n"                                \
-    "v_cndmask_b32_e32 %[resume], %[resume], %[t], vcc\n"      \
-    "v_cndmask_b32_e32 %[f], 0, %[f], vcc\n"                   \
     "v_fmac_f32_e32 %[ax], %[dx], %[f]\n"                      \
     "v_fmac_f32_e32 %[ay], %[dy], %[f]\n"                      \
-    "v_fmac_f32_e32 %[az], %[dz], %[f]\n"
+    "v_fmac_f32_e32 %[az], %[dz], %[f]\n"                      \
+    "s_mov_b64 exec, -1\n"
+#define NBMI_VISIT_A NBMI_VISIT("s36", "s37", "s38", "s39", "s40", "s41", "s42", "s[48:55]")
+#define NBMI_VISIT_B NBMI_VISIT("s48", "s49", "s50", "s51", "s52", "s53", "s54", "s[36:43]")
 
-__device__ __forceinline__ void visit4_asm(const Node *nodes, unsigned &off, float px, float py, float pz, float eps2,
-                                           unsigned &resume, float &ax, float &ay, float &az) {
+// walks from offset 0 until the cursor reaches `end` (> 0)
+__device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float px, float py, float pz, float eps2,
+                                         unsigned &resume, float &ax, float &ay, float &az) {
     float dx, dy, dz, d2, inv, f, t;
-    asm volatile(NBMI_VISIT_ASM NBMI_VISIT_ASM NBMI_VISIT_ASM NBMI_VISIT_ASM
+    unsigned off = 0u;
+    asm volatile("s_load_dwordx8 s[36:43], %[base], %[off]\n"
+                 "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc1 1b\n"
+                 "s_waitcnt lgkmcnt(0)\n"
                  : [off] "+s"(off), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az),
                    [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv), [f] "=&v"(f),
                    [t] "=&v"(t)
-                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2)
-                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "vcc", "scc");
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
+                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
 }
 
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     unsigned off = 0u;
 
     if (!kCount && !kGuard) {
-        while (off < nn) visit4_asm(nodes, off, px, py, pz, P.eps2, resume, ax, ay, az);
+        if (nn) walk_asm(nodes, nn, px, py, pz, P.eps2, resume, ax, ay, az);
     } else {
         unsigned long long wv = 0, lv = 0, la = 0, jm = 0;
         unsigned long long wm[4] = {0, 0, 0, 0};

@@ -8,7 +8,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbmi.so")
+LIB_PATH = os.environ.get("NBMI_LIB") or os.path.join(_HERE, "libnbmi.so")  # NBMI_LIB: A/B builds (measurement)
 
 _lib = None
 
