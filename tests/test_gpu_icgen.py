@@ -121,3 +121,23 @@ def test_record_with_device_ic(gpu, tmp_path):
     assert rec.get_completed_frames(d) == 4
     p, c = rec.load_frame(d, 3)
     assert p.shape == (5000, 3) and np.isfinite(p).all()
+
+
+def test_generated_edge_cases(gpu):
+    from nbody.gpu_backend import HIPBarnesHutSimulation, HIPDirectSimulation
+    with pytest.raises(ValueError):
+        HIPBarnesHutSimulation.generated("ring", 10, 100.0, 0.1, 1.0, 1.0)
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        HIPBarnesHutSimulation.generated("galaxy", -1, 100.0, 0.1, 1.0, 1.0)
+    e = HIPBarnesHutSimulation.generated("galaxy", 0, 100.0, 0.1, 1.0, 1.0)
+    e.step(0.1)
+    assert e.get_positions().shape == (0, 3)
+    one = HIPBarnesHutSimulation.generated("cluster", 1, 100.0, 0.1, 1.0, 1.0)
+    one.step(0.1)
+    assert np.isfinite(one.get_positions_f64()).all() and np.all(one.get_velocities() == 0.0)  # COM removed
+    odd = HIPBarnesHutSimulation.generated("collision", 1001, 2000.0, 0.08, 6.0, 1.0)  # halves of 500 / 501
+    p = odd.get_positions_f64()
+    assert (p[:500, 0] < 0).mean() > 0.99 and (p[500:, 0] > 0).mean() > 0.99
+    d = HIPDirectSimulation.generated("cluster", 3000, 300.0, 0.05, 1.0, 1.0, seed=5)
+    d.step(0.02)
+    assert np.isfinite(d.get_positions_f64()).all()

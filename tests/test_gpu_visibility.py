@@ -140,3 +140,38 @@ def test_visibility_one_million_bodies_and_timing(gpu, oracle):
     assert np.array_equal(vp, ref_p) and np.array_equal(vc, ref_c)
     print(f"visible {mask.sum()} of 1M: device cull+compact+D2H {1e3 * t_dev:.2f} ms; "
           f"fetch-all {1e3 * t_fetch:.2f} ms + CPU cull/gather {1e3 * t_cpu:.2f} ms")
+
+
+def test_visibility_edge_cases(gpu, oracle):
+    """Empty handles, a capacity smaller than the visible count, bodies exactly on the planes."""
+    import ctypes as C
+    import nbmi_native as nat
+    from boids.flock import Flock
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    z3 = np.zeros((0, 3))
+    empty = HIPBarnesHutSimulation(z3, z3, np.zeros(0), 1.0, 1.0, 1.0, 0.5)
+    p, c = empty.visible_points((0, 0, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0), 1.0, 1.0, 100.0)
+    assert p.shape == (0, 3) and c.shape == (0, 3)
+    # bodies on the near plane (z = 0.1 is visible: the test is z < 0.1), the far plane (z = far visible), the
+    # side planes (|x| < half_width is strict) - float64 exact values
+    pos = np.array([[0, 0, 0.1], [0, 0, 0.1], [0, 0, np.nextafter(0.1, 0)], [0, 0, 50.0], [0, 0, np.nextafter(50.0, 100)],
+                    [1.2 * 2.0, 0, 2.0], [np.nextafter(2.4, 0), 0, 2.0], [0, -np.nextafter(2.4, 0), 2.0]], dtype=np.float64)
+    sim = HIPBarnesHutSimulation(pos, np.zeros_like(pos), np.ones(len(pos)), 1.0, 1.0, 1.0, 0.5)
+    sim.compute_colors(15.0)
+    vp, _ = sim.visible_points((0, 0, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0), 1.0, 1.0, 50.0)
+    expect = np.array([True, True, False, True, False, False, True, True])
+    assert np.array_equal(expect, oracle.compute_visibility_points(pos, (0, 0, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0), 1.0, 1.0, 50.0))
+    assert np.array_equal(vp, pos[expect].astype(np.float32))
+    # capacity below the count: count is still reported, only `capacity` rows are written
+    lib, h = sim._lib, sim._h
+    cam = np.array([0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0], dtype=np.float64)
+    outp, outc = np.full((2, 3), -7, np.float32), np.full((2, 3), -7, np.float32)
+    cnt = C.c_int64(0)
+    nat.check(lib.nbmi_visible_points(h, nat.ptr(cam), 1.0, 1.0, 50.0, nat.ptr(outp), nat.ptr(outc), 2, C.addressof(cnt)), "vis")
+    assert cnt.value == expect.sum() and np.array_equal(outp, pos[expect][:2].astype(np.float32))
+    # count only
+    nat.check(lib.nbmi_visible_points(h, nat.ptr(cam), 1.0, 1.0, 50.0, None, None, 0, C.addressof(cnt)), "vis")
+    assert cnt.value == expect.sum()
+    fl = Flock(0, seed=1)
+    v, c = fl.visible_vertices((0, 0, 0), (0, 0, 1), (1, 0, 0), (0, 1, 0), fov=75, aspect=1.5)
+    assert len(v) == 0 and fl._visible_count == 0
