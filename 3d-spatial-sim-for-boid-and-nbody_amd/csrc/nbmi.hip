@@ -669,17 +669,18 @@ __global__ __launch_bounds__(kBlock) void k_pack_posm(Bodies cur, int64_t n, dou
 }
 
 template <int IB, bool kGuard, bool kIntegrate>
-__global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ posm, int64_t n, float eps2, Bodies cur,
-                                                   Bodies nxt, double *__restrict__ acc_out, double dt,
-                                                   double damping) {
+__global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ posm, int64_t n, int64_t ibeg, int64_t iend,
+                                                   float eps2, Bodies cur, Bodies nxt, double *__restrict__ acc_out,
+                                                   double dt, double damping) {
+    // bodies [ibeg, iend) (this launch's shard) against all n
     __shared__ float4 tile[kBlock];
-    const int64_t i0 = (int64_t)blockIdx.x * (kBlock * IB) + threadIdx.x;
+    const int64_t i0 = ibeg + (int64_t)blockIdx.x * (kBlock * IB) + threadIdx.x;
     float px[IB], py[IB], pz[IB];
     double ax[IB], ay[IB], az[IB];
 #pragma unroll
     for (int k = 0; k < IB; k++) {
         const int64_t i = i0 + (int64_t)k * kBlock;
-        const float4 p = i < n ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p = i < iend ? posm[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         px[k] = p.x; py[k] = p.y; pz[k] = p.z;
         ax[k] = ay[k] = az[k] = 0.0;
     }
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ po
 #pragma unroll
     for (int k = 0; k < IB; k++) {
         const int64_t i = i0 + (int64_t)k * kBlock;
-        if (i >= n) continue;
+        if (i >= iend) continue;
         if (kIntegrate) {
             const double vx = (cur.vx[i] + ax[k] * dt) * damping;
             const double vy = (cur.vy[i] + ay[k] * dt) * damping;
@@ -1119,17 +1120,22 @@ int launch_direct(nbmi_sim *s, double dt, double *acc_out) {
     k_pack_posm<<<nblocks(n), kBlock, 0, st>>>(cur, n, s->G, s->posm_s);
     const float eps2 = (float)(s->softening * s->softening);
     const bool guard = !(eps2 > 0.f);
+    // multi-GPU: a sharded handle integrates only the bodies [shard_begin, shard_end) (index order:
+    // the direct method never re-orders the state); the force pass always covers everything
+    const int64_t ibeg = kIntegrate ? s->shard_begin : 0, iend = kIntegrate ? s->shard_end : n;
+    const int64_t cnt = iend - ibeg;
+    if (cnt <= 0) return 0;
     // bodies per thread: enough blocks to cover 256 CUs a few times over
-    int ib = n >= 512 * 1024 ? 4 : (n >= 128 * 1024 ? 2 : 1);
+    int ib = cnt >= 512 * 1024 ? 4 : (cnt >= 128 * 1024 ? 2 : 1);
 #define NBMI_DIRECT(IBV)                                                                                      \
     do {                                                                                                      \
-        const int gb = (int)((n + (int64_t)kBlock * IBV - 1) / ((int64_t)kBlock * IBV));                      \
+        const int gb = (int)((cnt + (int64_t)kBlock * IBV - 1) / ((int64_t)kBlock * IBV));                    \
         if (guard)                                                                                            \
-            k_direct<IBV, true, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, eps2, cur, nxt, acc_out, dt, \
-                                                                  s->damping);                                \
+            k_direct<IBV, true, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, ibeg, iend, eps2, cur, nxt,  \
+                                                                  acc_out, dt, s->damping);                   \
         else                                                                                                  \
-            k_direct<IBV, false, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, eps2, cur, nxt, acc_out, dt, \
-                                                                   s->damping);                               \
+            k_direct<IBV, false, kIntegrate><<<gb, kBlock, 0, st>>>(s->posm_s, n, ibeg, iend, eps2, cur, nxt, \
+                                                                   acc_out, dt, s->damping);                  \
     } while (0)
     if (ib == 4) NBMI_DIRECT(4);
     else if (ib == 2) NBMI_DIRECT(2);

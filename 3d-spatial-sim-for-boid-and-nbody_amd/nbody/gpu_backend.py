@@ -195,6 +195,16 @@ class _HIPSimulation:
         k = int(cnt.value)
         return p[:k], c[:k]
 
+    # multi-GPU row exchange (device pointers; see nbody/sharded.py)
+    def set_shard(self, begin, end):
+        _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")
+
+    def export_shard(self, dev_ptr):
+        _nat.check(self._lib.nbmi_export_shard(self._h, int(dev_ptr)), "nbmi_export_shard")
+
+    def import_ranks(self, dev_ptr, begin, end):
+        _nat.check(self._lib.nbmi_import_ranks(self._h, int(dev_ptr), int(begin), int(end)), "nbmi_import_ranks")
+
     def enable_timers(self, on=True):
         _nat.check(self._lib.nbmi_enable_timers(self._h, 1 if on else 0), "nbmi_enable_timers")
 
@@ -283,15 +293,6 @@ class HIPBarnesHutSimulation(_HIPSimulation):
     def exchange_step(self, dev_runs, world, run_rows, dt):
         _nat.check(self._lib.nbmi_exchange_step(self._h, int(dev_runs), int(world), int(run_rows), float(dt)),
                    "nbmi_exchange_step")
-
-    def set_shard(self, begin, end):
-        _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")
-
-    def export_shard(self, dev_ptr):
-        _nat.check(self._lib.nbmi_export_shard(self._h, int(dev_ptr)), "nbmi_export_shard")
-
-    def import_ranks(self, dev_ptr, begin, end):
-        _nat.check(self._lib.nbmi_import_ranks(self._h, int(dev_ptr), int(begin), int(end)), "nbmi_import_ranks")
 
 
 class HIPDirectSimulation(_HIPSimulation):

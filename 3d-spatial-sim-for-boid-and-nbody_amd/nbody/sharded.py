@@ -41,12 +41,15 @@ def shard_bounds(n: int, world: int, rank: int):
 class HipShardEngine:
     """Shard engine on top of HIPBarnesHutSimulation; rows travel as torch CUDA tensors."""
 
-    def __init__(self, positions, velocities, masses, G, softening, damping, theta, device):
+    def __init__(self, positions, velocities, masses, G, softening, damping, theta, device, method="barnes_hut"):
         import torch
-        from .gpu_backend import HIPBarnesHutSimulation
+        from .gpu_backend import HIPBarnesHutSimulation, HIPDirectSimulation
         self.torch = torch
         self.device = torch.device("cuda", device)
-        self.sim = HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta, device=device)
+        if method == "direct":  # all-pairs: rows sharded by body index, same exchange
+            self.sim = HIPDirectSimulation(positions, velocities, masses, G, softening, damping, device=device)
+        else:
+            self.sim = HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta, device=device)
         self.n = self.sim.n
 
     def new_rows(self, rows):
@@ -87,18 +90,20 @@ class ShardedBarnesHut:
             self.engine.import_rows(self.full, self.n)
 
 
-def create_sharded_simulation(positions, velocities, masses, G, softening, damping, theta=0.5, mode="rows"):
+def create_sharded_simulation(positions, velocities, masses, G, softening, damping, theta=0.5, mode="rows",
+                              method="barnes_hut"):
     """Build the multi-GPU stepper from the torch.distributed environment (RANK/LOCAL_RANK/
     WORLD_SIZE).  Every rank passes the same full arrays.  mode: "rows" (stage 1, replicated state)
-    or "runs" (experimental run exchange with fixed ownership)."""
+    or "runs" (experimental run exchange with fixed ownership); method "direct" shards the all-pairs
+    kernel by body index through the same row exchange."""
     import os
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     import torch
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
-    if mode == "rows":
-        eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local)
+    if mode == "rows" or method == "direct":
+        eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local, method=method)
         return ShardedBarnesHut(eng, len(positions), rank, world, dist if world > 1 else None)
     if mode != "runs":
         raise ValueError(f"unknown sharding mode {mode!r}")

@@ -212,16 +212,17 @@ def main():
     if method == "boids":
         assert world == 1, "boids run as replicas only (DESIGN.md section 6)"
         return bench_boids(args, per_gpu, dt)
-    n_total = per_gpu * world
+    # Barnes-Hut: weak scaling (per_gpu bodies per rank); direct N^2: strong scaling (the same
+    # per_gpu bodies in total, rows sharded), since its work per body grows with N
+    n_total = per_gpu * world if method == "barnes_hut" else per_gpu
     p, v, m = make_ic(dist_name, n_total, R, G)
 
     from nbody import gpu_backend as gb
     with contextlib.redirect_stdout(sys.stderr):  # backend banners must not pollute the one JSON line
         if world > 1:
             from nbody.sharded import create_sharded_simulation
-            assert method == "barnes_hut"
             shard_mode = os.environ.get("NBMI_SHARD_MODE", "rows")  # "runs": experimental fixed-ownership exchange
-            sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode)
+            sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode, method=method)
             sim = sharded.engine.sim
             step = lambda k: sharded.step(dt, k)  # noqa: E731
         else:
@@ -254,7 +255,7 @@ def main():
         "unit": "body-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if method == "barnes_hut" else "strong", "vs_baseline": None,
         "dtype": "f32 forces, f64 state/keys",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": args.workload, "distribution": dist_name.replace("_fast", ""),
@@ -264,7 +265,9 @@ def main():
                                   (f"x{world}: fixed owners (initial key ranges), all-reduce max + all-gather of "
                                    "sorted 32-B runs per step, merged whole-system octree per rank"
                                    if os.environ.get("NBMI_SHARD_MODE", "rows") == "runs" else
-                                   f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows")},
+                                   (f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows"
+                                    if method == "barnes_hut" else
+                                    f"x{world}: body-index shards of the all-pairs kernel, all-gather of 64-B rows"))},
     }
 
     if world == 1 and rank == 0:

@@ -123,8 +123,9 @@ int nbmi_get_timers(nbmi_sim *sim, double *ms5, int64_t *count, int reset);
 int nbmi_walk_counters(nbmi_sim *sim, int64_t *out16);
 
 /* Multi-GPU (one process per GPU).  A handle created with nbmi_create holds ALL bodies; with a
- * shard set, step() integrates only the key-sorted ranks [begin,end) and leaves the others
- * untouched until nbmi_import_shard() supplies them.  Packed row = 8 doubles
+ * shard set, step() integrates only the key-sorted ranks [begin,end) (direct method: the body
+ * indices [begin,end), its state is never re-ordered) and leaves the others untouched until
+ * nbmi_import_ranks() supplies them.  Packed row = 8 doubles
  * {x,y,z,vx,vy,vz,m,id}.  Pointers are DEVICE pointers (e.g. torch tensors' data_ptr()) so the
  * exchange itself can be an RCCL all-gather issued by the host framework. */
 int nbmi_set_shard(nbmi_sim *sim, int64_t begin, int64_t end);

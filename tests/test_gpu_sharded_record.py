@@ -46,6 +46,32 @@ def test_virtual_shards_bit_identical_to_single_handle(gpu):
     assert np.array_equal(one.engine.sim.get_positions_f64(), ref_p)
 
 
+def test_direct_virtual_shards_bit_identical(gpu):
+    """All-pairs kernel sharded by body index through the same row exchange: three handles on one GPU."""
+    import torch
+    from nbody.gpu_backend import HIPDirectSimulation
+    from nbody.sharded import HipShardEngine, ShardedBarnesHut
+    g = golden("direct_cluster_2048")
+    n = 1999
+    pos, vel, mass = g["pos"][:n], g["vel"][:n], g["mass"][:n]
+    G, eps = float(g["G"]), float(g["eps"])
+    world = 3
+    single = HIPDirectSimulation(pos, vel, mass, G, eps, 1.0)
+    engines = [HipShardEngine(pos, vel, mass, G, eps, 1.0, 0.0, 0, method="direct") for _ in range(world)]
+    shards = [ShardedBarnesHut(e, n, r, world, dist=None) for r, e in enumerate(engines)]
+    for _ in range(4):
+        single.step(0.02)
+        for s in shards:
+            s.engine.step(0.02)
+            s.engine.export_rows(s.mine)
+        full = torch.cat([s.mine for s in shards], dim=0)
+        for s in shards:
+            s.engine.import_rows(full, n)
+    for e in engines:
+        assert np.array_equal(e.sim.get_positions_f64(), single.get_positions_f64())
+        assert np.array_equal(e.sim.get_velocities(), single.get_velocities())
+
+
 class _ThreadComm:
     """all_reduce_max / all_gather between `world` Python threads that play the ranks."""
 
