@@ -56,18 +56,21 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxLevel = 42;  // key digits available (2 x 21)
 
-// 32-byte octree node, DFS pre-order.  Loaded with one scalar s_load_dwordx8 per visit.
-struct alignas(32) Node {
+// 24-byte octree node, DFS pre-order, read by the walk with scalar loads.  The node that follows in
+// memory (first child, or for a leaf the next sibling) is always at own offset + 24, so only the
+// "skip my subtree" link is stored; 24 instead of 32 bytes per node is 25 % more nodes per cache
+// line (the walk slows by 30 % when the record is padded to 64 bytes: it is that sensitive).
+struct alignas(8) Node {
     float cx, cy, cz;   // centre of mass (leaf: the body's position)
     float gm;           // G * mass
     float s2t;          // (2*half_size)^2 / theta^2 (accept when s2t < dist_sq); 0 for leaves
-    unsigned next_off;  // BYTE offset (index * 32) of the first node after this node's subtree
-    unsigned seq_off;   // byte offset of the node that follows this one in memory (own offset + 32)
-    int ref;            // leaf: sorted rank of its body (>= 0); internal: ~(rank of first body)
+    unsigned next_off;  // BYTE offset (index * 24) of the first node after this node's subtree
 };
-// Node `num_nodes` is a sentinel that loops onto itself (next = seq = own offset, zero mass, at
-// "infinity"): the unrolled walk may step onto it a few times after the traversal has ended.
-static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
+constexpr unsigned kNodeBytes = 24;
+// Node `num_nodes` is a sentinel that loops onto itself (next = own offset, zero mass, at
+// "infinity", never opened): the unrolled walk may step onto it a few times after the traversal
+// has ended.  The walk reads 32 bytes per visit, so the array carries one spare row after it.
+static_assert(sizeof(Node) == kNodeBytes, "Node must be 24 bytes");
 
 struct Bodies {
     double *x, *y, *z, *vx, *vy, *vz, *m;
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const float4 *__restrict_
 __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
                                                         const float4 *__restrict__ posm_s, int64_t n, int64_t capacity,
                                                         Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
-                                                        int32_t *__restrict__ cell_r, uint8_t *__restrict__ cell_lev,
-                                                        TreeInfo *info) {
+                                                        int32_t *__restrict__ node_ref, int32_t *__restrict__ cell_r,
+                                                        uint8_t *__restrict__ cell_lev, TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r < n) {
         const int64_t total = n + (int64_t)Pex[n];
@@ -389,17 +392,17 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
             Node lf;
             lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
             lf.s2t = 0.0f;
-            lf.next_off = lf.seq_off = (unsigned)((idx + 1) << 5);
-            lf.ref = (int)r;
+            lf.next_off = (unsigned)(idx + 1) * kNodeBytes;
             nodes[idx] = lf;
+            node_ref[idx] = (int32_t)r;
             node_level[idx] = (uint8_t)leaf_level;
             if (r == 0) {
                 Node sn;
                 sn.cx = sn.cy = sn.cz = 1.0e30f;
                 sn.gm = 0.f; sn.s2t = 0.f;
-                sn.next_off = sn.seq_off = (unsigned)(total << 5);
-                sn.ref = -1;
+                sn.next_off = (unsigned)total * kNodeBytes;
                 nodes[total] = sn;
+                node_ref[total] = -1;
             }
         }
     }
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
                                                        const int32_t *__restrict__ cell_r, const uint8_t *__restrict__ cell_lev,
                                                        int64_t n, double G, double inv_theta2, int64_t capacity,
                                                        Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
-                                                       const TreeInfo *__restrict__ info) {
+                                                       int32_t *__restrict__ node_ref, const TreeInfo *__restrict__ info) {
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t ncells = Pex[n];
     if (q >= ncells || n + ncells + 1 > capacity) return;
@@ -467,10 +470,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
     nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
     nd.gm = (float)M;  // the moments are sums of G*m
     nd.s2t = (float)(size * size * inv_theta2);
-    nd.next_off = (unsigned)((e + (int64_t)Pex[e]) << 5);
-    nd.seq_off = (unsigned)((idx + 1) << 5);
-    nd.ref = ~(int)r;
+    nd.next_off = (unsigned)(e + (int64_t)Pex[e]) * kNodeBytes;
     nodes[idx] = nd;
+    node_ref[idx] = (int32_t)r;
     node_level[idx] = (uint8_t)lev;
 }
 
@@ -522,8 +524,8 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     const unsigned long long any_open = m_active & ~m_geom;
     active_out = active;
     force_out = take && (dist_sq > eps2);
-    jumped = !any_open && nd.next_off != nd.seq_off;
-    return any_open ? nd.seq_off : nd.next_off;
+    jumped = !any_open && nd.next_off != off + kNodeBytes;
+    return any_open ? off + kNodeBytes : nd.next_off;
 }
 
 // Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 5 scalar
@@ -534,12 +536,13 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 // all-ones again before the next visit (every launched wave is full; lanes without a body carry
 // resume = ~0 and never take part).  The node record of the NEXT visit is requested as soon as its offset
 // is known - before the nine force instructions of the current visit are issued - into the other
-// of two SGPR banks (A = s[36:43], B = s[48:55]: cx cy cz gm s2t next_off seq_off ref), which
+// of two SGPR banks (A = s[36:43], B = s[48:55]: cx cy cz gm s2t next_off + 8 spare bytes), which
 // takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
 // asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
 // a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
-#define NBMI_VISIT(CX, CY, CZ, GM, S2T, NXT, SEQ, NEXTBANK)    \
+#define NBMI_VISIT(CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI)   \
     "v_cmpx_ge_u32_e64 s[44:45], %[off], %[resume]\n"          \
+    "s_add_u32 s58, %[off], 24\n"                              \
     "s_waitcnt lgkmcnt(0)\n"                                   \
     "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
     "v_sub_f32_e32 %[dy], " CY ", %[py]\n"                     \
@@ -549,8 +552,9 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
     "v_cmpx_lt_i32_e64 s[46:47], " S2T ", %[d2]\n"             \
     "s_andn2_b64 s[56:57], s[44:45], s[46:47]\n"               \
-    "s_cselect_b32 %[off], " SEQ ", " NXT "\n"                 \
-    "s_load_dwordx8 " NEXTBANK ", %[base], %[off]\n"           \
+    "s_cselect_b32 %[off], s58, " NXT "\n"                     \
+    "s_load_dwordx4 " NEXTLO ", %[base], %[off]\n"             \
+    "s_load_dwordx2 " NEXTHI ", %[base], %[off] offset:16\n"   \
     "v_rsq_f32_e32 %[inv], %[d2]\n"                            \
     "v_mov_b32_e32 %[resume], " NXT "\n"                       \
     "v_mul_f32_e32 %[f], " GM ", %[inv]\n"                     \
@@ -560,15 +564,16 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "v_fmac_f32_e32 %[ay], %[dy], %[f]\n"                      \
     "v_fmac_f32_e32 %[az], %[dz], %[f]\n"                      \
     "s_mov_b64 exec, -1\n"
-#define NBMI_VISIT_A NBMI_VISIT("s36", "s37", "s38", "s39", "s40", "s41", "s42", "s[48:55]")
-#define NBMI_VISIT_B NBMI_VISIT("s48", "s49", "s50", "s51", "s52", "s53", "s54", "s[36:43]")
+#define NBMI_VISIT_A NBMI_VISIT("s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
+#define NBMI_VISIT_B NBMI_VISIT("s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
 
 // walks from offset 0 until the cursor reaches `end` (> 0)
 __device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float px, float py, float pz, float eps2,
                                          unsigned &resume, float &ax, float &ay, float &az) {
     float dx, dy, dz, d2, inv, f, t;
     unsigned off = 0u;
-    asm volatile("s_load_dwordx8 s[36:43], %[base], %[off]\n"
+    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc1 1b\n"
@@ -578,7 +583,7 @@ __device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float 
                    [t] "=&v"(t)
                  : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
                  : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
-                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory");
+                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
 }
 
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     const int lane = threadIdx.x & 63;
     const int64_t rank = P.rank_begin + (int64_t)lb * kBlock + threadIdx.x;
     const bool valid = rank < P.rank_end;
-    const unsigned nn = (info_in->error != 0) ? 0u : ((unsigned)info_in->num_nodes << 5);  // end offset
+    const unsigned nn = (info_in->error != 0) ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);  // end offset
 
     float px = 0.f, py = 0.f, pz = 0.f;
     if (valid) {
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         int wbase[4] = {-1000, -1000, -1000, -1000};
         while (off < nn) {
             bool a_, f_, j_;
-            const int c_old = (int)(off >> 5);
+            const int c_old = (int)(off / kNodeBytes);
             off = visit<kGuard>(nodes, off, px, py, pz, P.eps2, resume, ax, ay, az, a_, f_, j_);
             if (kCount) {
                 wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0;
@@ -829,13 +834,12 @@ __global__ __launch_bounds__(kBlock) void k_order(const uint32_t *__restrict__ p
     if (r < n) out[r] = id[perm[r]];
 }
 
-__global__ __launch_bounds__(kBlock) void k_cells(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
+__global__ __launch_bounds__(kBlock) void k_cells(const int32_t *__restrict__ node_ref, const uint8_t *__restrict__ node_level,
                                                   const uint64_t *__restrict__ hi_s, int64_t num_nodes,
                                                   int32_t *__restrict__ level, uint64_t *__restrict__ key) {
     const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (u >= num_nodes) return;
-    const Node nd = nodes[u];
-    const int r = nd.ref >= 0 ? nd.ref : ~nd.ref;
+    const int r = node_ref[u];  // first body of the node's range
     const int lev = node_level[u];
     level[u] = lev;
     key[u] = lev <= 21 ? (lev == 0 ? 0ull : (hi_s[r] >> (63 - 3 * lev))) : ~0ull;
@@ -959,6 +963,7 @@ struct nbmi_sim {
     ScanVal *tile_sum = nullptr;
     Node *nodes = nullptr;
     uint8_t *node_level = nullptr;
+    int32_t *node_ref = nullptr;  // first body (sorted rank) of every node; queries only
     int32_t *cell_r = nullptr;  // internal-cell list: first body and level
     uint8_t *cell_lev = nullptr;
     int64_t node_capacity = 0;
@@ -1061,11 +1066,11 @@ int enqueue_global_tree(nbmi_sim *s) {
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->node_capacity, s->nodes,
-                                                 s->node_level, s->cell_r, s->cell_lev, s->info);
+                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->info);
     // one thread per internal cell; the count lives on the device, so launch for the row budget
     k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
                                                                   n, s->G, inv_theta2, s->node_capacity, s->nodes,
-                                                                  s->node_level, s->info);
+                                                                  s->node_level, s->node_ref, s->info);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1205,8 +1210,8 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
-            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity) ||
-            dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
+            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity + 2) ||
+            dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->node_ref, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
             dev_alloc(s, &s->cell_lev, s->node_capacity - n))
             return -2;
         s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
@@ -1547,7 +1552,7 @@ int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity)
     uint64_t *dk = nullptr;
     NBMI_HIP_CHECK(hipMalloc((void **)&dl, (size_t)nn * 4));
     NBMI_HIP_CHECK(hipMalloc((void **)&dk, (size_t)nn * 8));
-    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->nodes, s->node_level, s->t_hi, nn, dl, dk);
+    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->node_ref, s->node_level, s->t_hi, nn, dl, dk);
     hipError_t e1 = hipMemcpyAsync(level, dl, (size_t)nn * 4, hipMemcpyDeviceToHost, s->stream);
     hipError_t e2 = hipMemcpyAsync(key, dk, (size_t)nn * 8, hipMemcpyDeviceToHost, s->stream);
     hipError_t e3 = hipStreamSynchronize(s->stream);
@@ -1640,7 +1645,8 @@ int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_ro
     if (dev_alloc(s, &s->t_hi, nt) || dev_alloc(s, &s->t_lo, nt) || dev_alloc(s, &s->t_posm, nt) ||
         dev_alloc(s, &s->delta, nt) || dev_alloc(s, &s->cnt, nt + 1) || dev_alloc(s, &s->Pex, nt + 1) ||
         dev_alloc(s, &s->S, nt + 1) || dev_alloc(s, &s->tile_sum, (nt + 1) / kScanTile + 2) ||
-        dev_alloc(s, &s->nodes, s->node_capacity) || dev_alloc(s, &s->node_level, s->node_capacity) ||
+        dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->node_level, s->node_capacity) ||
+        dev_alloc(s, &s->node_ref, s->node_capacity) ||
         dev_alloc(s, &s->cell_r, s->node_capacity - nt) || dev_alloc(s, &s->cell_lev, s->node_capacity - nt))
         return NBMI_ERR_HIP;
     s->nt = nt;

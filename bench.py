@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 importlib.import_module("3d-spatial-sim-for-boid-and-nbody_amd")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-NODE_BYTES = 32        # one octree node record per wave-level visit
+NODE_BYTES = 24  # csrc/nbmi.hip Node
 BODY_BYTES_WALK = 156  # walk kernel per body: reads posm 16 + perm 4 + state 60, writes 60 (+16 slack)
 
 WORKLOADS = {
