@@ -69,7 +69,7 @@ struct alignas(8) Node {
 constexpr unsigned kNodeBytes = 24;
 // Node `num_nodes` is a sentinel that loops onto itself (next = own offset, zero mass, at
 // "infinity", never opened): the unrolled walk may step onto it a few times after the traversal
-// has ended.  The walk reads 32 bytes per visit, so the array carries one spare row after it.
+// has ended.
 static_assert(sizeof(Node) == kNodeBytes, "Node must be 24 bytes");
 
 struct Bodies {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 
 // ---------------------------------------------------------------------------------------
 // K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor over the
-// pre-order node array (one scalar s_load_dwordx8 per visit); per lane the reference's test
+// pre-order node array (scalar loads of the 24-byte record); per lane the reference's test
 // (simulation.py:245-274):
 //     d = com - p; dist_sq = |d|^2 + eps^2;
 //     accept if leaf or 2 hs / dist < theta          [== (2hs)^2/theta^2 < dist_sq; leaves carry 0]
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 // The reference's explicit "skip my own leaf" needs no instruction here: the own leaf has d = 0
 // exactly, so its term is 0 (eps > 0) or fails the dist_sq > eps^2 guard (kGuard, eps == 0).
 // `resume` = first node index at which the lane takes part again (it accepted an ancestor of
-// everything before that).  The cursor moves to seq_off if any lane opens the node, else to
+// everything before that).  The cursor moves to the next node in memory if any lane opens the node, else to
 // next_off.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
 // written at the body's NEW sorted rank (state re-ordering is fused into this kernel).
 // ---------------------------------------------------------------------------------------
@@ -529,14 +529,14 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 }
 
 // Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 5 scalar
-// instructions per visit.  One s_load_dwordx8 at an SGPR byte offset.  The two compares are
+// instructions per visit.  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.  The two compares are
 // v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those that TAKE the node,
 // so the force instructions and the `resume` update need no per-lane selects; s_andn2 of the two
-// masks leaves "some lane opens" in SCC for the s_cselect that picks seq_off / next_off; EXEC is
+// masks leaves "some lane opens" in SCC for the s_cselect that picks off + 24 / next_off; EXEC is
 // all-ones again before the next visit (every launched wave is full; lanes without a body carry
 // resume = ~0 and never take part).  The node record of the NEXT visit is requested as soon as its offset
 // is known - before the nine force instructions of the current visit are issued - into the other
-// of two SGPR banks (A = s[36:43], B = s[48:55]: cx cy cz gm s2t next_off + 8 spare bytes), which
+// of two SGPR banks (A = s[36:41], B = s[48:53]: cx cy cz gm s2t next_off), which
 // takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
 // asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
 // a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
