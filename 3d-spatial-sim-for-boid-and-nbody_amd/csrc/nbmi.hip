@@ -595,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                                                  TreeInfo *info_out) {
     const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
     const int lane = threadIdx.x & 63;
-    const int64_t rank = P.rank_begin + (int64_t)lb * kBlock + threadIdx.x;
+    const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
     const bool valid = rank < P.rank_end;
     const unsigned nn = (info_in->error != 0) ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);  // end offset
 
@@ -984,6 +984,7 @@ struct nbmi_sim {
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
+    int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {};
@@ -1104,9 +1105,10 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
-    const int gb = nblocks(cntr);
+    const int wb = s->walk_block;
+    const int gb = (int)((cntr + wb - 1) / wb);
 #define NBMI_WALK(I, C, G) \
-    k_walk<I, C, G><<<gb, kBlock, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
+    k_walk<I, C, G><<<gb, wb, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
     if (integrate) {
         if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
     } else {
@@ -1266,6 +1268,10 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
     if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);  // tuning knob (measurement only)
+    if (const char *e = getenv("NBMI_WALK_BLOCK")) {
+        const int b = atoi(e);
+        if (b == 64 || b == 128 || b == 256) s->walk_block = b;
+    }
     if (create_impl(s, pos, vel, mass) != 0) {
         std::string keep = nbmi::get_error();
         nbmi_destroy(s);

@@ -212,9 +212,11 @@ def main():
     if method == "boids":
         assert world == 1, "boids run as replicas only (DESIGN.md section 6)"
         return bench_boids(args, per_gpu, dt)
-    # Barnes-Hut: weak scaling (per_gpu bodies per rank); direct N^2: strong scaling (the same
-    # per_gpu bodies in total, rows sharded), since its work per body grows with N
-    n_total = per_gpu * world if method == "barnes_hut" else per_gpu
+    # default workload: weak scaling (per_gpu bodies per rank).  Strong scaling (the same bodies in
+    # total, sharded) for the direct N^2 kernel, whose work per body grows with N, and for
+    # BASELINE config 4, which is "10 M bodies across the GPUs of one node".
+    strong = method != "barnes_hut" or args.workload == "collision_10m_bh"
+    n_total = per_gpu if strong else per_gpu * world
     p, v, m = make_ic(dist_name, n_total, R, G)
 
     from nbody import gpu_backend as gb
@@ -255,11 +257,11 @@ def main():
         "unit": "body-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak" if method == "barnes_hut" else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32 forces, f64 state/keys",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": args.workload, "distribution": dist_name.replace("_fast", ""),
-                   "bodies_per_gpu": per_gpu, "bodies_total": n_total, "theta": theta, "dt": dt, "G": G,
+                   "bodies_per_gpu": n_total // world if strong else per_gpu, "bodies_total": n_total, "theta": theta, "dt": dt, "G": G,
                    "softening": eps, "spawn_radius": R, "method": method,
                    "parallelism": "single GPU" if world == 1 else
                                   (f"x{world}: fixed owners (initial key ranges), all-reduce max + all-gather of "
