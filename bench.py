@@ -297,6 +297,13 @@ def main():
                                "wave_visits_per_group": wc["wave_visits"] / max(1, (n_total + 63) // 64),
                                "lane_visits_per_body": wc["lane_visits"] / n_total,
                                "interactions_per_s": wc["lane_accepts"] / (walk_ms * 1e-3),
+                               # second reading: this kernel is bound by vector-instruction issue and
+                               # its per-wave load chain, not by HBM: 16 VALU instructions per wave-level visit at the
+                               # measured 2.8 cycles per instruction per SIMD (scripts/ubench), 1024 SIMDs, 2.4 GHz
+                               "valu_issue": {"valu_per_visit": 16, "cycles_per_valu": 2.8,
+                                              "cycles_per_visit_per_simd": walk_ms * 1e-3 * 2.4e9 * 1024 / max(1, wc["wave_visits"]),
+                                              "frac": 16 * 2.8 * wc["wave_visits"] / (walk_ms * 1e-3 * 2.4e9 * 1024)},
+                               "lane_efficiency": wc["lane_visits"] / max(1, 64 * wc["wave_visits"]),
                                "num_nodes": ts["num_nodes"], "max_depth": ts["max_depth"],
                                "window_misses_per_group": {str(k): v / max(1, (n_total + 63) // 64)
                                                            for k, v in wc["window_misses"].items()},
