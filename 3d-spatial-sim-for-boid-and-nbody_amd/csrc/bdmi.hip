@@ -13,6 +13,7 @@
 // sweep kernel tests the occupancy bit (L2 resident) before touching the pair table, reads
 // neighbours from B and writes the updated boid back to A at the same rank, physics fused.
 #include <stddef.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -75,33 +76,50 @@ __global__ __launch_bounds__(kBlock) void k_reorder(Boids a, BoidsAoS b, const u
     b.id[r] = a.id[j];
 }
 
-// build_cell_lists (flock.py:47-65) from sorted keys.  The first boid of a cell sets the cell's bit
-// in a 1-bit-per-cell occupancy map (1 MB at the reference grid: L2 resident, cleared per step
-// instead of a 33 MB table) and writes the cell's {start, end} pair; empty cells are never read.
-__global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
-                                                  uint32_t *__restrict__ occ, int2 *__restrict__ cell_range) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint32_t word = 0xffffffffu, bits = 0u;
-    if (r < n) {
-        const uint32_t c = keys_s[r];
-        word = c >> 5;
-        if (r == 0 || keys_s[r - 1] != c) {  // first boid of its cell
-            int64_t e = r + 1;
-            while (e < n && keys_s[e] == c) e++;
-            cell_range[c] = make_int2((int)r, (int)e);
-            bits = 1u << (c & 31);
-        }
-    }
-    // cells of one occupancy word are adjacent in the sorted order: OR their bits inside the wave
-    // (segmented by word) so that only the first lane of each segment issues an atomic
+// build_cell_lists (flock.py:47-65) from sorted keys, as a COMPACT table: the non-empty cells are
+// numbered in cell order (rank k), cell_start[k] = first sorted boid of the k-th non-empty cell
+// (its end is cell_start[k + 1]); occ[w] = {bits, prefix}: one bit per cell of the 32 cells of word w
+// (non-empty or not) and the rank of the word's first non-empty cell, so that one 8-byte load gives
+//     rank(cell) = occ[cell >> 5].prefix + popcount(occ[cell >> 5].bits & ((1 << (cell & 31)) - 1)).
+// 2 MB + 4 B per non-empty cell, all cache resident; the table indexed by cell (66 MB at the
+// reference grid, one random 128-byte line per lookup) was where the sweep's HBM traffic came from.
+// Two passes over the sorted keys (count "first boid of a cell" per tile, scan, emit).
+__device__ __forceinline__ bool first_of_cell(const uint32_t *keys_s, int64_t r, int64_t n) {
+    return r < n && (r == 0 || keys_s[r - 1] != keys_s[r]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_first_count(const uint32_t *__restrict__ keys_s, int64_t n,
+                                                        uint32_t *__restrict__ tile_cnt) {
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * vis::kItems;
+    unsigned c = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t ob = __shfl_down(bits, d), ow = __shfl_down(word, d);
-        if (lane + d < 64 && ow == word) bits |= ob;
+    for (int k = 0; k < vis::kItems; k++) c += first_of_cell(keys_s, base + k, n) ? 1u : 0u;
+    unsigned total;
+    (void)vis::block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ keys_s, int64_t n,
+                                                  const uint32_t *__restrict__ tile_cnt, int64_t ntiles,
+                                                  uint2 *__restrict__ occ, int32_t *__restrict__ cell_start) {
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * vis::kItems;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < vis::kItems; k++) m |= (first_of_cell(keys_s, base + k, n) ? 1u : 0u) << k;
+    unsigned total;
+    unsigned rank = tile_cnt[blockIdx.x] + vis::block_exclusive_scan(__popc(m), &total);
+#pragma unroll
+    for (int k = 0; k < vis::kItems; k++) {
+        if (!((m >> k) & 1u)) continue;
+        const int64_t r = base + k;
+        const uint32_t c = keys_s[r];
+        cell_start[rank] = (int32_t)r;
+        // few same-address collisions: at most 32 cells share a word, usually 1-6 of them non-empty
+        atomicOr(&occ[c >> 5].x, 1u << (c & 31));
+        if (r == 0 || (keys_s[r - 1] >> 5) != (c >> 5)) occ[c >> 5].y = rank;
+        rank++;
     }
-    const uint32_t pw = __shfl_up(word, 1);
-    if (bits != 0u && (lane == 0 || pw != word)) atomicOr(&occ[word], bits);
+    if (blockIdx.x == 0 && threadIdx.x == 0) cell_start[tile_cnt[ntiles]] = (int32_t)n;  // end of the last cell
 }
 
 // number of non-empty cells of the last grid; on demand only (bdmi_grid_info), one atomic per block
@@ -140,14 +158,27 @@ __device__ __forceinline__ bool steer(double &x, double &y, double &z, double vx
     return true;
 }
 
+// XCD-aware block remap (same idea as the tree walk's): hardware deals consecutive blocks round-robin
+// over the 8 XCDs, each with its own L2.  A boid's candidates sit up to ~grid_dim^2 * density ranks
+// away in the cell-sorted order (the cz +- 1 planes), so each XCD gets one CONTIGUOUS eighth of the
+// blocks and finds them in its own L2 instead of re-fetching them from HBM.  xcd_contiguous = 0
+// keeps the hardware order (measurement knob BDMI_XCD=0).
+__device__ __forceinline__ int64_t logical_block(int b, int nb, int xcd_contiguous) {
+    if (!xcd_contiguous) return b;
+    const int xcd = b & 7, j = b >> 3;
+    const int q = nb >> 3, rem = nb & 7;
+    return (int64_t)xcd * q + (xcd < rem ? xcd : rem) + j;
+}
+
 // compute_flocking_spatial (flock.py:68-238) + update_physics_numba (flock.py:241-308).
 // kPhysics=false: write the four force arrays (caller's boid order) instead of integrating.
 template <bool kPhysics>
-__global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uint32_t *__restrict__ occ,
-                                                  const int2 *__restrict__ cell_range, int64_t n, GridP g, FlockP P,
+__global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uint2 *__restrict__ occ,
+                                                  const int32_t *__restrict__ cell_start, int64_t n, GridP g, FlockP P,
                                                   double *__restrict__ o_sep, double *__restrict__ o_ali,
-                                                  double *__restrict__ o_coh, double *__restrict__ o_avg) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                  double *__restrict__ o_coh, double *__restrict__ o_avg,
+                                                  int xcd_contiguous) {
+    const int64_t r = logical_block(blockIdx.x, gridDim.x, xcd_contiguous) * kBlock + threadIdx.x;
     if (r >= n) return;
     const double4 pi4 = b.p[r], vi4 = b.v[r], ci4 = b.c[r];
     const double pix = pi4.x, piy = pi4.y, piz = pi4.z;
@@ -156,39 +187,59 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
     const int cx = cell_coord(pix, g), cy = cell_coord(piy, g), cz = cell_coord(piz, g);
     double sx = 0, sy = 0, sz = 0, alx = 0, aly = 0, alz = 0, cox = 0, coy = 0, coz = 0, clr = 0, clg = 0, clb = 0;
     int sep_count = 0, nb_count = 0;
-    // same visiting order as the reference: dcx outermost, dcz innermost (flock.py:117-132)
-    for (int dcx = -g.range; dcx <= g.range; dcx++) {
-        const int ncx = cx + dcx;
-        if (ncx < 0 || ncx >= g.dim) continue;
+    // The reference visits the (2 range + 1)^3 neighbour cells one by one (flock.py:117-132).  Cells that
+    // differ only in x have consecutive indices, and boids are sorted by cell index, so the candidates
+    // of one (y, z) row of cells are ONE contiguous run of sorted boids: (2 range + 1)^2 runs instead of
+    // (2 range + 1)^3 cell visits, found with two rank lookups in the compact table.  Same candidate
+    // set as the reference; the floating-point sums run in a different order (the reference's own
+    // order inside a cell is unspecified anyway: np.argsort, flock.py:618).
+    const int x_lo = cx - g.range < 0 ? 0 : cx - g.range;
+    const int x_hi = cx + g.range > g.dim - 1 ? g.dim - 1 : cx + g.range;
+    for (int dcz = -g.range; dcz <= g.range; dcz++) {
+        const int ncz = cz + dcz;
+        if (ncz < 0 || ncz >= g.dim) continue;
         for (int dcy = -g.range; dcy <= g.range; dcy++) {
             const int ncy = cy + dcy;
             if (ncy < 0 || ncy >= g.dim) continue;
-            for (int dcz = -g.range; dcz <= g.range; dcz++) {
-                const int ncz = cz + dcz;
-                if (ncz < 0 || ncz >= g.dim) continue;
-                const int64_t cell = ncx + (int64_t)ncy * g.dim + (int64_t)ncz * g.dim * g.dim;
-                if (!((occ[cell >> 5] >> (cell & 31)) & 1u)) continue;  // empty cell: no table read
-                const int2 range = cell_range[cell];
-                for (int32_t q = range.x; q < range.y; q++) {
-                    if (q == r) continue;
-                    const double4 qp = b.p[q];
-                    const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
-                    const double dist_sq = dx * dx + dy * dy + dz * dz;
-                    if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
-                        const double dist = sqrt(dist_sq);
-                        if (dist_sq < P.separation_sq) {
-                            const double inv_dist = 1.0 / dist;
-                            sx += dx * inv_dist / dist;
-                            sy += dy * inv_dist / dist;
-                            sz += dz * inv_dist / dist;
-                            sep_count++;
-                        }
-                        const double4 qv = b.v[q], qc = b.c[q];
-                        alx += qv.x; aly += qv.y; alz += qv.z;
-                        cox += qp.x; coy += qp.y; coz += qp.z;
-                        clr += qc.x; clg += qc.y; clb += qc.z;
-                        nb_count++;
+            const int64_t row = (int64_t)ncy * g.dim + (int64_t)ncz * g.dim * g.dim;
+            const int64_t c_lo = row + x_lo, c_hi = row + x_hi;
+            // first and last non-empty cell of [c_lo, c_hi]
+            int first = -1, last = -1;  // bit positions inside their words
+            uint2 first_w = make_uint2(0u, 0u), last_w = make_uint2(0u, 0u);
+            for (int64_t w = c_lo >> 5; w <= (c_hi >> 5); w++) {
+                const uint2 e = occ[w];
+                uint32_t bits = e.x;
+                if (w == (c_lo >> 5)) bits &= ~0u << (c_lo & 31);
+                if (w == (c_hi >> 5)) bits &= ~0u >> (31 - (c_hi & 31));
+                if (bits) {
+                    if (first < 0) { first = __ffs(bits) - 1; first_w = e; }
+                    last = 31 - __clz(bits);
+                    last_w = e;
+                }
+            }
+            if (first < 0) continue;  // the whole row is empty: no table read
+            const uint32_t k_lo = first_w.y + __popc(first_w.x & ((1u << first) - 1u));
+            const uint32_t k_hi = last_w.y + __popc(last_w.x & ((1u << last) - 1u)) + 1u;
+            const int32_t q_begin = cell_start[k_lo], q_end = cell_start[k_hi];
+            for (int32_t q = q_begin; q < q_end; q++) {
+                if (q == r) continue;
+                const double4 qp = b.p[q];
+                const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
+                const double dist_sq = dx * dx + dy * dy + dz * dz;
+                if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
+                    const double dist = sqrt(dist_sq);
+                    if (dist_sq < P.separation_sq) {
+                        const double inv_dist = 1.0 / dist;
+                        sx += dx * inv_dist / dist;
+                        sy += dy * inv_dist / dist;
+                        sz += dz * inv_dist / dist;
+                        sep_count++;
                     }
+                    const double4 qv = b.v[q], qc = b.c[q];
+                    alx += qv.x; aly += qv.y; alz += qv.z;
+                    cox += qp.x; coy += qp.y; coz += qp.z;
+                    clr += qc.x; clg += qc.y; clb += qc.z;
+                    nb_count++;
                 }
             }
         }
@@ -281,13 +332,15 @@ struct bdmi_flock {
     Boids A = {};
     BoidsAoS B = {};
     uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *perm = nullptr;
-    uint32_t *occ = nullptr;       // 1 bit per cell
-    int2 *cell_range = nullptr;    // {start, end} of non-empty cells
+    uint2 *occ = nullptr;          // per 32 cells: {occupancy bits, rank of the first non-empty cell}
+    int32_t *cell_start = nullptr;    // first sorted boid of the k-th non-empty cell; [count] = n
+    uint32_t *tile_cnt = nullptr;     // scan scratch
     int64_t occ_words = 0;
     unsigned long long *occupied = nullptr;
     void *tmp_sort = nullptr;
     size_t tmp_sort_bytes = 0;
     double *stage = nullptr;  // 12 N doubles
+    int xcd_contiguous = 1;   // sweep block -> XCD mapping, see logical_block()
     // render-side reduction scratch (bdmi_visible_vertices), allocated on first use
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
@@ -349,8 +402,13 @@ int enqueue_grid(bdmi_flock *f, bool timed) {
                                             (size_t)n, 0, f->key_bits, st));
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[1], st));
     k_reorder<<<nblocks(n), kBlock, 0, st>>>(f->A, f->B, f->perm, n);
-    NBMI_HIP_CHECK(hipMemsetAsync(f->occ, 0, (size_t)f->occ_words * sizeof(uint32_t), st));
-    k_table<<<nblocks(n), kBlock, 0, st>>>(f->keys_s, n, f->occ, f->cell_range);
+    NBMI_HIP_CHECK(hipMemsetAsync(f->occ, 0, (size_t)f->occ_words * sizeof(uint2), st));
+    {
+        const int64_t ntiles = vis::tiles_for(n);
+        k_first_count<<<(int)ntiles, kBlock, 0, st>>>(f->keys_s, n, f->tile_cnt);
+        vis::k_scan_tiles<<<1, vis::kBlock, 0, st>>>(f->tile_cnt, ntiles);
+        k_table<<<(int)ntiles, kBlock, 0, st>>>(f->keys_s, n, f->tile_cnt, ntiles, f->occ, f->cell_start);
+    }
     if (timed) NBMI_HIP_CHECK(hipEventRecord(f->ev[2], st));
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
@@ -384,7 +442,8 @@ static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, c
         return -2;
     if (dev_alloc(f, &f->keys, n) || dev_alloc(f, &f->keys_s, n) || dev_alloc(f, &f->idx, n) ||
         dev_alloc(f, &f->perm, n) || dev_alloc(f, &f->occ, (size_t)f->occ_words) ||
-        dev_alloc(f, &f->cell_range, (size_t)f->num_cells) || dev_alloc(f, &f->occupied, 1) ||
+        dev_alloc(f, &f->cell_start, (size_t)n + 2) ||
+        dev_alloc(f, &f->tile_cnt, (size_t)vis::tiles_for(n) + 2) || dev_alloc(f, &f->occupied, 1) ||
         dev_alloc(f, &f->stage, (size_t)12 * (n ? n : 1)))
         return -2;
     f->tmp_sort_bytes = nbmi::sort_pairs32_temp_bytes((size_t)n, 0, f->key_bits);
@@ -425,6 +484,7 @@ bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const d
         return nullptr;
     }
     bdmi_flock *f = new bdmi_flock();
+    if (const char *e = getenv("BDMI_XCD")) f->xcd_contiguous = atoi(e) != 0;  // measurement knob
     f->n = n;
     f->device = device;
     memcpy(f->params, params, sizeof(f->params));
@@ -458,8 +518,8 @@ int bdmi_step(bdmi_flock *f, double dt, int substeps) {
     const FlockP P = make_params(f, dt);
     for (int k = 0; k < substeps; k++) {
         if (int rc = enqueue_grid(f, f->timers)) return rc;
-        k_flock<true><<<nblocks(f->n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_range, f->n, f->grid, P,
-                                                               nullptr, nullptr, nullptr, nullptr);
+        k_flock<true><<<nblocks(f->n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_start, f->n, f->grid, P,
+                                                               nullptr, nullptr, nullptr, nullptr, f->xcd_contiguous);
         NBMI_HIP_CHECK(hipGetLastError());
         if (f->timers) {
             NBMI_HIP_CHECK(hipEventRecord(f->ev[3], f->stream));
@@ -539,8 +599,8 @@ int bdmi_get_forces(bdmi_flock *f, double *sep, double *ali, double *coh, double
     if (int rc = enqueue_grid(f, false)) return rc;
     double *d0 = f->stage, *d1 = d0 + 3 * n, *d2 = d1 + 3 * n, *d3 = d2 + 3 * n;
     const FlockP P = make_params(f, 0.0);
-    k_flock<false><<<nblocks(n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_range, n, f->grid, P, d0, d1,
-                                                         d2, d3);
+    k_flock<false><<<nblocks(n), kBlock, 0, f->stream>>>(f->B, f->A, f->occ, f->cell_start, n, f->grid, P, d0, d1,
+                                                         d2, d3, f->xcd_contiguous);
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipMemcpyAsync(sep, d0, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
     NBMI_HIP_CHECK(hipMemcpyAsync(ali, d1, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
