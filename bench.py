@@ -141,12 +141,13 @@ def bench_boids(args, n, dt):
     k = max(1, tm["steps"])
     sweep_ms = tm["sweep_ms"] / k
     info = fl.grid_info()
-    # algorithmic bytes of the sweep kernel per boid: own AoS records 96 r + SoA state 76 w, 27 occupancy
-    # words (4 B), one {start,end} pair (8 B) per non-empty neighbour cell, candidates x 32 B position
-    # records (+64 B velocity/colour for the ~1 in range)
+    # algorithmic bytes of the sweep kernel per boid: own AoS records 96 r + SoA state 76 w; per (y,z)
+    # row of neighbour cells (9 of them) one 8-byte occupancy entry, and for a non-empty row two 4-byte
+    # run bounds; candidates x 32 B position records (+64 B velocity/colour for the ~1 in range)
     occ_frac = info["occupied"] / info["num_cells"]
     cand = 27.0 * n / info["num_cells"]
-    alg = n * (96 + 76 + 27 * 4 + 27 * occ_frac * 8 + cand * 32.0 + 1.0 * 64.0)
+    row_occ = 1.0 - (1.0 - occ_frac) ** 3
+    alg = n * (96 + 76 + 9 * 8 + 9 * row_occ * 8 + cand * 32.0 + 1.0 * 64.0)
     ach = alg / (sweep_ms * 1e-3) / 1e9
     out = {"metric": "boid-steps/sec (boids sep/align/cohesion sweep)", "value": n * args.steps / elapsed,
            "unit": "boid-steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
