@@ -108,17 +108,25 @@ __global__ __launch_bounds__(kBlock) void k_table(const uint32_t *__restrict__ k
     for (int k = 0; k < vis::kItems; k++) m |= (first_of_cell(keys_s, base + k, n) ? 1u : 0u) << k;
     unsigned total;
     unsigned rank = tile_cnt[blockIdx.x] + vis::block_exclusive_scan(__popc(m), &total);
+    // a thread's 8 consecutive boids usually fall into one or two occupancy words: OR their bits
+    // locally and issue one atomic per word
+    uint32_t pend_word = 0xffffffffu, pend_bits = 0u;
 #pragma unroll
     for (int k = 0; k < vis::kItems; k++) {
         if (!((m >> k) & 1u)) continue;
         const int64_t r = base + k;
         const uint32_t c = keys_s[r];
         cell_start[rank] = (int32_t)r;
-        // few same-address collisions: at most 32 cells share a word, usually 1-6 of them non-empty
-        atomicOr(&occ[c >> 5].x, 1u << (c & 31));
+        if ((c >> 5) != pend_word) {
+            if (pend_bits) atomicOr(&occ[pend_word].x, pend_bits);
+            pend_word = c >> 5;
+            pend_bits = 0u;
+        }
+        pend_bits |= 1u << (c & 31);
         if (r == 0 || (keys_s[r - 1] >> 5) != (c >> 5)) occ[c >> 5].y = rank;
         rank++;
     }
+    if (pend_bits) atomicOr(&occ[pend_word].x, pend_bits);
     if (blockIdx.x == 0 && threadIdx.x == 0) cell_start[tile_cnt[ntiles]] = (int32_t)n;  // end of the last cell
 }
 
