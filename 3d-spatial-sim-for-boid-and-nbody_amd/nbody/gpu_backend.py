@@ -182,7 +182,8 @@ class _HIPSimulation:
     def visible_points(self, cam_pos, cam_forward, cam_right, cam_up, tan_h, tan_v, far_dist):
         """Frustum culling + compaction on the device (reference compute_visibility_points,
         nbody/simulation.py:403-434, and the gather of draw(), :927-928): returns
-        (positions[mask] float32, colors[mask] float32) in body order - only these rows leave the GPU."""
+        (positions[mask] float32, colors[mask] float32) in body order - only these rows leave the GPU.
+        The two arrays are views into buffers this object re-uses: valid until the next call."""
         cam = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64).reshape(3) for a in
                                                    (cam_pos, cam_forward, cam_right, cam_up)]))
         cnt = C.c_int64(0)
