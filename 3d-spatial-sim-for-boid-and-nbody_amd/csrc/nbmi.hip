@@ -67,6 +67,12 @@ struct alignas(8) Node {
     unsigned next_off;  // BYTE offset (index * 24) of the first node after this node's subtree
 };
 constexpr unsigned kNodeBytes = 24;
+// Node links are 32-bit byte offsets: at most 2^32 / 24 rows.  The reference allocates min(8 M, 4N)
+// rows (simulation.py:477) and uses ~1.5 N; this build allocates 4N + 4096 rows up to that ceiling,
+// which still leaves 1.7 N rows at the largest supported body count.
+constexpr int64_t kMaxNodeRows = 178000000;
+constexpr int64_t kMaxBodies = 100000000;  // the reference's largest presets have 50 M bodies
+inline int64_t node_rows_for(int64_t n) { return 4 * n + 4096 < kMaxNodeRows ? 4 * n + 4096 : kMaxNodeRows; }
 // Node `num_nodes` is a sentinel that loops onto itself (next = own offset, zero mass, at
 // "infinity", never opened): the unrolled walk may step onto it a few times after the traversal
 // has ended.
@@ -1208,7 +1214,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, sizeof(TreeInfo), s->stream));
     NBMI_HIP_CHECK(hipMemsetAsync(s->colors, 0, (size_t)(n ? n : 1) * 3 * sizeof(float), s->stream));
     if (s->method == NBMI_METHOD_BARNES_HUT) {
-        s->node_capacity = 4 * n + 4096;  // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N
+        s->node_capacity = node_rows_for(n);  // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
@@ -1243,7 +1249,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
 nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const double *mass, double G,
                       double softening, double damping, double theta, int method, int device) {
     nbmi::clear_error();
-    if (n < 0 || n > 30000000 || (n > 0 && (!pos || !vel || !mass))) {
+    if (n < 0 || n > kMaxBodies || (n > 0 && (!pos || !vel || !mass))) {
         nbmi::set_error("nbmi_create: bad arguments (n=%lld)", (long long)n);
         return nullptr;
     }
@@ -1284,7 +1290,7 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
 nbmi_sim *nbmi_create_generated(int distribution, int64_t n, double spawn_radius, uint64_t seed, double G,
                                 double softening, double damping, double theta, int method, int device) {
     nbmi::clear_error();
-    if (n < 0 || n > 30000000 || distribution < NBMI_IC_GALAXY || distribution > NBMI_IC_CLUSTER ||
+    if (n < 0 || n > kMaxBodies || distribution < NBMI_IC_GALAXY || distribution > NBMI_IC_CLUSTER ||
         (method != NBMI_METHOD_BARNES_HUT && method != NBMI_METHOD_DIRECT) || !(softening >= 0.0) || !(theta >= 0.0) ||
         !(spawn_radius > 0.0)) {
         nbmi::set_error("nbmi_create_generated: bad arguments (n=%lld, distribution=%d)", (long long)n, distribution);
@@ -1640,13 +1646,13 @@ int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_ro
     if (int rc = check_handle(s)) return rc;
     if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
     if (s->world > 0) { nbmi::set_error("nbmi_exchange_enable: already enabled"); return NBMI_ERR_ARG; }
-    if (world < 1 || run_rows < s->n || n_total < s->n || n_total > (int64_t)world * run_rows || n_total > 30000000) {
+    if (world < 1 || run_rows < s->n || n_total < s->n || n_total > (int64_t)world * run_rows || n_total > kMaxBodies) {
         nbmi::set_error("nbmi_exchange_enable: bad sizes (n=%lld, n_total=%lld, world=%d, run_rows=%lld)",
                         (long long)s->n, (long long)n_total, world, (long long)run_rows);
         return NBMI_ERR_ARG;
     }
     const int64_t nt = n_total;
-    s->node_capacity = 4 * nt + 4096;
+    s->node_capacity = node_rows_for(nt);
     // tree workspace for the whole system (the n-sized arrays of nbmi_create stay for the local sort)
     if (dev_alloc(s, &s->t_hi, nt) || dev_alloc(s, &s->t_lo, nt) || dev_alloc(s, &s->t_posm, nt) ||
         dev_alloc(s, &s->delta, nt) || dev_alloc(s, &s->cnt, nt + 1) || dev_alloc(s, &s->Pex, nt + 1) ||

@@ -33,7 +33,7 @@ typedef struct nbmi_sim nbmi_sim;
 #define NBMI_ERR_ARG (-1)
 #define NBMI_ERR_HIP (-2)
 #define NBMI_ERR_NODEV (-3)
-#define NBMI_ERR_CAPACITY (-4) /* octree needs more than the 4N node rows the reference allocates */
+#define NBMI_ERR_CAPACITY (-4) /* octree needs more node rows than allocated (4N, at most 178 M) */
 
 /* Number of visible HIP devices (0 if none / no driver).  Replaces the probe in
  * detect_backend()/_check_cuda(), nbody/gpu_backend.py:36-70. */

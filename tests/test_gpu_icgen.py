@@ -141,3 +141,24 @@ def test_generated_edge_cases(gpu):
     d = HIPDirectSimulation.generated("cluster", 3000, 300.0, 0.05, 1.0, 1.0, seed=5)
     d.step(0.02)
     assert np.isfinite(d.get_positions_f64()).all()
+
+
+def test_fifty_million_body_preset_fits(gpu):
+    """The reference's largest presets ("50 Million Star Galaxy": theta 1.5, G 0.04, eps 10, R 3000,
+    dt 0.35; tools/presets.py:2479-2493) on one GPU: generated on the device, stepped, octree inside its
+    row budget (the reference itself loses bodies beyond its 8 M-node cap)."""
+    from tools.presets import generate_distribution_device
+    n = 50_000_000
+    sim = generate_distribution_device("galaxy", n, 3000.0, 0.04, 10.0, theta=1.5, seed=1)
+    sim.sync()
+    t0 = time.perf_counter()
+    sim.step_many(0.35, 2)
+    sim.sync()
+    dt = (time.perf_counter() - t0) / 2
+    st = sim.tree_stats()
+    assert n < st["num_nodes"] < 1.7 * n
+    p = sim.get_positions()
+    assert p.shape == (n, 3) and np.isfinite(p).all()
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        generate_distribution_device("galaxy", 100_000_001, 3000.0, 0.04, 10.0)
+    print(f"50 M bodies, theta 1.5: {1e3 * dt:.1f} ms/step, {st['num_nodes']} nodes, depth {st['max_depth']}")
