@@ -498,6 +498,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 // ---------------------------------------------------------------------------------------
 struct WalkParams {
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
+
     float eps2;
     int xcd_chunk;  // see logical_block()
     double dt, damping;
@@ -663,6 +664,119 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         const int64_t o = 3 * (int64_t)cur.id[j];
         acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Split walk for small systems.  Below ~250 k bodies there are fewer groups than wave slots and the
+// step time is ONE wave's serial chain of ~1 700 dependent visits (0.32 ms at 100 k bodies, where
+// the same work spread over the chip would take 0.1 ms).  Here a block of K waves shares one group
+// of 64 bodies and wave w walks the w-th K-th of the pre-order array, [w N/K, (w+1) N/K) nodes.
+// (Measured at 100 k bodies, K = 4: equal quarters 0.179 ms; quarters centred on the group's own
+// leaves with a near range of 1/8 ... 1/8192 of the array 0.204 ... 0.257 ms - a galaxy's far field
+// is where most visits are, so plain equal parts balance best, and they do not depend on the
+// group.)  A part that starts at S needs every lane's `resume` as the full walk would have it
+// there: only the ancestors of S can have set it beyond S, so seek() replays the opening test down
+// that chain (no forces: an ancestor lies before S and belongs to another part).  The K partial
+// sums meet in LDS and are added in fixed order, then the usual fused kick-drift.  Same accepted
+// (body, node) set as the one-wave walk; the fp32 sums associate differently (by fixed node ranges,
+// so a body's result still does not depend on its group or on the sharding).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned seek(const Node *__restrict__ nodes, unsigned S, float px, float py, float pz,
+                                         float eps2, unsigned &resume) {
+    unsigned off = 0u;
+    while (off < S) {
+        off = __builtin_amdgcn_readfirstlane(off);
+        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
+        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
+        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
+        const bool active = resume <= off;
+        const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
+        if (active && geom) resume = nd.next_off;
+        if (__builtin_amdgcn_ballot_w64(active && !geom) == 0ull) {
+            off = nd.next_off;  // nobody opens this ancestor: the walk never enters it
+            continue;
+        }
+        // descend to the child whose subtree contains S
+        unsigned c = off + kNodeBytes;
+        for (;;) {
+            c = __builtin_amdgcn_readfirstlane(c);
+            const unsigned nxt = reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + c)->next_off;
+            if (nxt > S) break;
+            c = nxt;
+        }
+        off = c;
+    }
+    return off;
+}
+
+// one visit per loop test: a part must not step past its end (the next part starts there)
+__device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin, unsigned end, float px, float py,
+                                               float pz, float eps2, unsigned &resume, float &ax, float &ay, float &az) {
+    float dx, dy, dz, d2, inv, f, t;
+    unsigned off = begin;
+    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
+                 "1:\n" NBMI_VISIT_A
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 2f\n" NBMI_VISIT_B
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc1 1b\n"
+                 "2:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : [off] "+s"(off), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv), [f] "=&v"(f),
+                   [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
+                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ nodes, const TreeInfo *info_in,
+                                                       const float4 *__restrict__ posm_s,
+                                                       const uint32_t *__restrict__ perm, Bodies cur, Bodies nxt,
+                                                       WalkParams P) {
+    __shared__ float part[K][3][64];
+    const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t rank = P.rank_begin + (int64_t)lb * 64 + lane;
+    const bool valid = rank < P.rank_end;
+    const int64_t num_nodes = (info_in->error != 0) ? 0 : info_in->num_nodes;
+
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) {
+        const float4 p = posm_s[rank];
+        px = p.x; py = p.y; pz = p.z;
+    }
+    unsigned resume = valid ? 0u : 0xffffffffu;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    // wave-uniform range (w is the wave index): tell the compiler so
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * w / K) * kNodeBytes);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * (w + 1) / K) * kNodeBytes);
+    if (lo < hi) {
+        const unsigned c0 = __builtin_amdgcn_readfirstlane(lo == 0u ? 0u : seek(nodes, lo, px, py, pz, P.eps2, resume));
+        if (c0 < hi) walk_range_asm(nodes, c0, hi, px, py, pz, P.eps2, resume, ax, ay, az);
+    }
+    part[w][0][lane] = ax; part[w][1][lane] = ay; part[w][2][lane] = az;
+    __syncthreads();
+    if (w != 0 || !valid) return;
+    ax = part[0][0][lane]; ay = part[0][1][lane]; az = part[0][2][lane];
+#pragma unroll
+    for (int k = 1; k < K; k++) {
+        ax += part[k][0][lane]; ay += part[k][1][lane]; az += part[k][2][lane];
+    }
+    const uint32_t j = perm[rank];
+    double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+    const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
+    const int32_t id0 = cur.id[j];
+    vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
+    vx *= P.damping; vy *= P.damping; vz *= P.damping;
+    nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
+    nxt.x[rank] = x0 + vx * P.dt;
+    nxt.y[rank] = y0 + vy * P.dt;
+    nxt.z[rank] = z0 + vz * P.dt;
+    nxt.m[rank] = m0;
+    nxt.id[rank] = id0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -991,6 +1105,7 @@ struct nbmi_sim {
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
+    int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
     // timers
     bool timers = false;
     hipEvent_t ev[6] = {};
@@ -1111,6 +1226,25 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
+
+    // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on
+    // the size of the tree (not on the shard), so that every sharding adds up the same partial sums.
+    const int64_t tree_groups = (s->nt + 63) / 64, groups = (cntr + 63) / 64;
+    // measured (galaxy, 10 k ... 300 k bodies): the largest K <= 16 with groups x K <= ~9 400 waves is the
+    // fastest or within 5 % of it; beyond ~280 k bodies the one-wave walk wins
+    int parts = 1;
+    while (parts < 16 && tree_groups <= 4300 && tree_groups * parts * 2 <= s->split_max_waves) parts *= 2;
+    if (integrate && !guard && s->world == 0 && parts > 1) {
+#define NBMI_SPLIT(KV) \
+    k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, P)
+        if (parts == 2) NBMI_SPLIT(2);
+        else if (parts == 4) NBMI_SPLIT(4);
+        else if (parts == 8) NBMI_SPLIT(8);
+        else NBMI_SPLIT(16);
+#undef NBMI_SPLIT
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const int wb = s->walk_block;
     const int gb = (int)((cntr + wb - 1) / wb);
 #define NBMI_WALK(I, C, G) \
@@ -1274,6 +1408,7 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
     if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);  // tuning knob (measurement only)
+    if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_BLOCK")) {
         const int b = atoi(e);
         if (b == 64 || b == 128 || b == 256) s->walk_block = b;
