@@ -83,7 +83,7 @@ class ShardedBarnesHut:
     def step(self, dt, substeps=1):
         for _ in range(substeps):
             self.engine.step(dt)
-            if self.world == 1:
+            if self.dist is None:  # one rank, no process group: nothing to exchange
                 continue
             self.engine.export_rows(self.mine)
             self.dist.all_gather_into_tensor(self.full, self.mine)
@@ -104,7 +104,8 @@ def create_sharded_simulation(positions, velocities, masses, G, softening, dampi
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
     if mode == "rows" or method == "direct":
         eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local, method=method)
-        return ShardedBarnesHut(eng, len(positions), rank, world, dist if world > 1 else None)
+        # (a process group of one rank still runs the collective: used to smoke-test RCCL on a 1-GPU box)
+        return ShardedBarnesHut(eng, len(positions), rank, world, dist if dist.is_initialized() else None)
     if mode != "runs":
         raise ValueError(f"unknown sharding mode {mode!r}")
     eng = HipRunEngine(positions, velocities, masses, G, softening, damping, theta, local, rank, world)

@@ -195,9 +195,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     dev = local % max(1, ndev)  # == LOCAL_RANK on a real node; lets ranks share a GPU in rehearsals
-    if world > 1:
+    # NBMI_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, shard engine, collective) with a
+    # single rank - the RCCL smoke test a 1-GPU box allows
+    use_dist = world > 1 or os.environ.get("NBMI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(dev)
         backend = os.environ.get("NBMI_BENCH_BACKEND", "nccl")  # "gloo": 1-GPU rehearsal of the N>1 path
         if backend == "nccl":
@@ -222,7 +226,7 @@ def main():
 
     from nbody import gpu_backend as gb
     with contextlib.redirect_stdout(sys.stderr):  # backend banners must not pollute the one JSON line
-        if world > 1:
+        if use_dist:
             from nbody.sharded import create_sharded_simulation
             shard_mode = os.environ.get("NBMI_SHARD_MODE", "rows")  # "runs": experimental fixed-ownership exchange
             sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode, method=method)
@@ -236,7 +240,7 @@ def main():
     def fence():
         sim.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -246,7 +250,7 @@ def main():
     step(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -321,7 +325,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
