@@ -1094,6 +1094,7 @@ struct nbmi_sim {
     void *stage = nullptr;    // getter staging, 3N doubles
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
+    bool exchange_sync = true;  // export / import block the host (false: the caller orders streams itself)
     // octree inputs in key order.  Normally the handle's own sorted arrays (nt == n); with the run
     // exchange enabled, the merge of every rank's run (nt = bodies of the whole system).
     int64_t nt = 0;
@@ -1760,7 +1761,7 @@ int nbmi_export_shard(nbmi_sim *s, void *dev_rows) {
     if (!dev_rows) { nbmi::set_error("null device buffer"); return NBMI_ERR_ARG; }
     k_pack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], s->shard_begin, s->shard_end, (double *)dev_rows);
     NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
@@ -1772,7 +1773,7 @@ int nbmi_import_ranks(nbmi_sim *s, const void *dev_rows, int64_t begin, int64_t 
     if (!dev_rows) { nbmi::set_error("null device buffer"); return NBMI_ERR_ARG; }
     k_unpack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], begin, end, (const double *)dev_rows);
     NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->tree_valid = false;
     return 0;
 }
@@ -1902,6 +1903,12 @@ int nbmi_visible_points(nbmi_sim *s, const double *cam12, double tan_h, double t
         NBMI_HIP_CHECK(hipMemcpyAsync(out_col, d_col, (size_t)rows * 12, hipMemcpyDeviceToHost, st));
         NBMI_HIP_CHECK(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int nbmi_set_exchange_sync(nbmi_sim *s, int sync) {
+    if (int rc = check_handle(s)) return rc;
+    s->exchange_sync = sync != 0;
     return 0;
 }
 

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "nbmi_exchange_export": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nbmi_exchange_step": (C.c_int, [_vp, _vp, C.c_int, _i64, _dbl]),
     "nbmi_visible_points": (C.c_int, [_vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),
+    "nbmi_set_exchange_sync": (C.c_int, [_vp, C.c_int]),
     "nbmi_stream": (_vp, [_vp]),
     "bdmi_create": (_vp, [_i64, _vp, _vp, _vp, _vp, C.c_int]),
     "bdmi_destroy": (None, [_vp]),

@@ -200,6 +200,9 @@ class _HIPSimulation:
     def set_shard(self, begin, end):
         _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")
 
+    def set_exchange_sync(self, sync: bool):
+        _nat.check(self._lib.nbmi_set_exchange_sync(self._h, 1 if sync else 0), "nbmi_set_exchange_sync")
+
     def export_shard(self, dev_ptr):
         _nat.check(self._lib.nbmi_export_shard(self._h, int(dev_ptr)), "nbmi_export_shard")
 

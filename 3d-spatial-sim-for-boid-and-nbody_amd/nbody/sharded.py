@@ -25,6 +25,8 @@ can be exercised on CPU (gloo) with a stand-in engine:
     set_shard(begin, end) / step(dt) / export_rows(out) / import_rows(full, n_rows)
 ``HipShardEngine`` is the real one (device pointers into libnbmi.so).
 """
+import os
+
 import numpy as np
 
 ROW = 8  # doubles per packed body row (include/nbmi.h nbmi_export_shard)
@@ -51,6 +53,7 @@ class HipShardEngine:
         else:
             self.sim = HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta, device=device)
         self.n = self.sim.n
+        self.stream = None
 
     def new_rows(self, rows):
         return self.torch.zeros((rows, ROW), dtype=self.torch.float64, device=self.device)
@@ -61,11 +64,21 @@ class HipShardEngine:
     def step(self, dt):
         self.sim.step(dt)
 
+    def share_stream(self):
+        """Make the library's own HIP stream torch's current stream for the exchange: the
+        collective is then ordered after the pack kernel and before the unpack kernel by the
+        stream itself, and a step needs no host synchronisation.  Returns the torch stream."""
+        if self.stream is None:
+            self.stream = self.torch.cuda.ExternalStream(self.sim.stream_handle(), device=self.device)
+            self.sim.set_exchange_sync(False)
+        return self.stream
+
     def export_rows(self, out):
-        self.sim.export_shard(out.data_ptr())  # synchronises the library stream
+        self.sim.export_shard(out.data_ptr())  # synchronises the library stream unless it is shared
 
     def import_rows(self, full, n_rows):
-        self.torch.cuda.current_stream(self.device).synchronize()  # collective finished
+        if self.stream is None:
+            self.torch.cuda.current_stream(self.device).synchronize()  # collective finished
         self.sim.import_ranks(full.data_ptr(), 0, n_rows)
 
 
@@ -79,8 +92,23 @@ class ShardedBarnesHut:
         engine.set_shard(self.begin, self.end)
         self.mine = engine.new_rows(self.per)
         self.full = engine.new_rows(self.per * world)
+        # device collectives (RCCL): run them on the library's own stream; gloo / stand-in engines keep
+        # the host-synchronised path
+        self.shared = None
+        if dist is not None and hasattr(engine, "share_stream") and dist.get_backend() == "nccl" \
+                and os.environ.get("NBMI_EXCHANGE_SYNC", "0") != "1":
+            self.shared = engine.share_stream()
 
     def step(self, dt, substeps=1):
+        if self.dist is not None and self.shared is not None:
+            # everything - kernels, pack, collective, unpack - is enqueued in order on the library's stream
+            with self.engine.torch.cuda.stream(self.shared):
+                for _ in range(substeps):
+                    self.engine.step(dt)
+                    self.engine.export_rows(self.mine)
+                    self.dist.all_gather_into_tensor(self.full, self.mine)
+                    self.engine.import_rows(self.full, self.n)
+            return
         for _ in range(substeps):
             self.engine.step(dt)
             if self.dist is None:  # one rank, no process group: nothing to exchange

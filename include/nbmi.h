@@ -165,6 +165,10 @@ int nbmi_exchange_step(nbmi_sim *sim, const void *dev_runs, int world, int64_t r
  * part crosses PCIe. */
 int nbmi_visible_points(nbmi_sim *sim, const double *cam12, double tan_h, double tan_v, double far_dist,
                         float *out_positions_xyz, float *out_colors_rgb, int64_t capacity, int64_t *count);
+/* nbmi_export_shard / nbmi_import_ranks synchronise the handle's stream by default.  With sync = 0 they
+ * only enqueue: for callers that issue their collective ON the handle's stream (nbmi_stream; e.g.
+ * torch.cuda.ExternalStream), so that a step needs no host synchronisation at all. */
+int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 

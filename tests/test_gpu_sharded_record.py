@@ -72,6 +72,35 @@ def test_direct_virtual_shards_bit_identical(gpu):
         assert np.array_equal(e.sim.get_velocities(), single.get_velocities())
 
 
+def test_rccl_one_rank_group_stream_ordered_exchange(gpu):
+    """The production exchange path with the real RCCL backend, as far as one GPU allows: a process
+    group of one rank, rows packed / all-gathered / unpacked on the library's own stream (no host
+    synchronisation inside a step).  Must equal the plain handle bit for bit."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from nbody.sharded import HipShardEngine, ShardedBarnesHut
+    g = golden("tree_galaxy_2048")
+    pos, vel, mass = g["pos"], g["vel"], g["mass"]
+    G, eps = float(g["G"]), float(g["eps"])
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        sh = ShardedBarnesHut(HipShardEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0), len(pos), 0, 1, dist)
+        assert sh.shared is not None  # stream-ordered path selected for the nccl backend
+        sh.step(0.05, 7)
+        sh.engine.sim.sync()
+        single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
+        single.step_many(0.05, 7)
+        assert np.array_equal(sh.engine.sim.get_positions_f64(), single.get_positions_f64())
+        assert np.array_equal(sh.engine.sim.get_velocities(), single.get_velocities())
+    finally:
+        dist.destroy_process_group()
+
+
 class _ThreadComm:
     """all_reduce_max / all_gather between `world` Python threads that play the ranks."""
 
