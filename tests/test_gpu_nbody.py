@@ -73,6 +73,47 @@ def test_accelerations(gpu, oracle, name, theta, key):
     sim.close()
 
 
+@pytest.mark.parametrize("theta", [0.0, 1.3, 1.5, 2.5])
+def test_extreme_theta(gpu, oracle, theta):
+    """theta as coarse as the reference's presets go (1.3-1.5; beyond 2/sqrt(3) = 1.15 bodies accept cells
+    that contain themselves, the root included: reference quirk, simulation.py:259-261) and theta = 0
+    (never accept a cell: direct sum through the tree).  Forces, accepted-pair counts and one step of
+    both product kernels (split walk for this size, one-wave walk with it switched off)."""
+    g = golden("tree_collision_2048")
+    pos, vel, mass = g["pos"], g["vel"], g["mass"]
+    G, eps = float(g["G"]), float(g["eps"])
+    b = oracle.compute_bounds(pos)
+    nd = oracle.NodeArrays.for_bodies(len(pos))
+    nn = oracle.build_octree(pos, mass, b, nd)
+    ref, st = oracle.compute_forces_barnes_hut(pos, mass, nd, nn, theta, G, eps, stats=True)
+    sim = _bh(gpu, pos, vel, mass, G, eps, theta=theta)
+    acc = sim.accelerations()
+    scale = np.linalg.norm(ref, axis=1).max()
+    err = np.abs(acc - ref).max() / scale
+    wc = sim.walk_counters()
+    print(f"theta={theta}: max err {err:.2e}, accepts {wc['lane_accepts']} vs {st['accepted']}, "
+          f"visits/body {wc['lane_visits'] / len(pos):.1f}")
+    # coarse theta: a flipped tie costs one big cell's truncation error, hence the looser bound there
+    assert err <= (2e-4 if theta <= 1.0 else 5e-3)
+    assert abs(wc["lane_accepts"] - st["accepted"]) <= max(2, 2e-4 * st["accepted"])
+    if theta == 0.0:
+        assert wc["lane_accepts"] == len(pos) * (len(pos) - 1) == st["accepted"]  # every other body, exactly
+    o = oracle.BHStepper(pos, vel, mass, theta, G, eps, 1.0)
+    o.step(0.05)
+    sim.step(0.05)
+    tol = (2e-4 if theta <= 1.0 else 5e-3) * scale * 0.05 ** 2 + 1e-12
+    assert np.abs(sim.get_positions_f64() - o.pos).max() <= tol
+    import os
+    os.environ["NBMI_SPLIT_WAVES"] = "0"
+    try:
+        one = _bh(gpu, pos, vel, mass, G, eps, theta=theta)
+    finally:
+        del os.environ["NBMI_SPLIT_WAVES"]
+    one.step(0.05)
+    assert np.abs(one.get_positions_f64() - o.pos).max() <= tol
+    sim.close(); one.close()
+
+
 def test_edge_cases(gpu, oracle):
     g = golden("tree_edge_cases")
     for tag in ["n1", "n2", "lattice", "close_pairs", "heavy"]:
