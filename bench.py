@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--workload", default="galaxy_1m_bh", choices=sorted(WORKLOADS))
     ap.add_argument("--bodies-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--theta", type=float, default=None,
+                    help="override the workload's opening angle (exploration; BASELINE's metric is theta = 0.5)")
     args = ap.parse_args()
 
     import torch
@@ -214,6 +216,8 @@ def main():
     dist_name, per_gpu, R, G, eps, theta, dt, method = WORKLOADS[args.workload]
     if args.bodies_per_gpu:
         per_gpu = args.bodies_per_gpu
+    if args.theta is not None:
+        theta = args.theta
     if method == "boids":
         assert world == 1, "boids run as replicas only (DESIGN.md section 6)"
         return bench_boids(args, per_gpu, dt)
@@ -256,7 +260,7 @@ def main():
         elapsed = float(tmax.item())
 
     out = {
-        "metric": "body-steps/sec (N-body Barnes-Hut, theta=0.5)" if method == "barnes_hut"
+        "metric": f"body-steps/sec (N-body Barnes-Hut, theta={theta:g})" if method == "barnes_hut"
                   else "body-steps/sec (N-body direct N^2)",
         "value": n_total * args.steps / elapsed,
         "unit": "body-steps/s",
