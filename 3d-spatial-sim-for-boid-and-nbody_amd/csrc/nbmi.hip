@@ -501,6 +501,7 @@ struct WalkParams {
 
     float eps2;
     int xcd_chunk;  // see logical_block()
+    int pair;       // one-wave walk with two cursors (the two halves of the array)
     double dt, damping;
 };
 
@@ -547,10 +548,10 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 // takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
 // asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
 // a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
-#define NBMI_VISIT(CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI)   \
-    "v_cmpx_ge_u32_e64 s[44:45], %[off], %[resume]\n"          \
-    "s_add_u32 s58, %[off], 24\n"                              \
-    "s_waitcnt lgkmcnt(0)\n"                                   \
+#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI) \
+    "v_cmpx_ge_u32_e64 s[44:45], " OFF ", " RES "\n"           \
+    "s_add_u32 s58, " OFF ", 24\n"                             \
+    WAIT                                                       \
     "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
     "v_sub_f32_e32 %[dy], " CY ", %[py]\n"                     \
     "v_sub_f32_e32 %[dz], " CZ ", %[pz]\n"                     \
@@ -559,20 +560,33 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
     "v_cmpx_lt_i32_e64 s[46:47], " S2T ", %[d2]\n"             \
     "s_andn2_b64 s[56:57], s[44:45], s[46:47]\n"               \
-    "s_cselect_b32 %[off], s58, " NXT "\n"                     \
-    "s_load_dwordx4 " NEXTLO ", %[base], %[off]\n"             \
-    "s_load_dwordx2 " NEXTHI ", %[base], %[off] offset:16\n"   \
+    "s_cselect_b32 " OFF ", s58, " NXT "\n"                    \
+    "s_load_dwordx4 " NEXTLO ", %[base], " OFF "\n"            \
+    "s_load_dwordx2 " NEXTHI ", %[base], " OFF " offset:16\n"  \
     "v_rsq_f32_e32 %[inv], %[d2]\n"                            \
-    "v_mov_b32_e32 %[resume], " NXT "\n"                       \
+    "v_mov_b32_e32 " RES ", " NXT "\n"                         \
     "v_mul_f32_e32 %[f], " GM ", %[inv]\n"                     \
     "v_mul_f32_e32 %[t], %[inv], %[inv]\n"                     \
     "v_mul_f32_e32 %[f], %[f], %[t]\n"                         \
-    "v_fmac_f32_e32 %[ax], %[dx], %[f]\n"                      \
-    "v_fmac_f32_e32 %[ay], %[dy], %[f]\n"                      \
-    "v_fmac_f32_e32 %[az], %[dz], %[f]\n"                      \
+    "v_fmac_f32_e32 %[ax" ACC "], %[dx], %[f]\n"               \
+    "v_fmac_f32_e32 %[ay" ACC "], %[dy], %[f]\n"               \
+    "v_fmac_f32_e32 %[az" ACC "], %[dz], %[f]\n"               \
     "s_mov_b64 exec, -1\n"
-#define NBMI_VISIT_A NBMI_VISIT("s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
-#define NBMI_VISIT_B NBMI_VISIT("s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
+#define NBMI_WAIT "s_waitcnt lgkmcnt(0)\n"
+#define NBMI_VISIT_A \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
+#define NBMI_VISIT_B \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
+// two cursors in one wave (walk_pair_asm): cursor 1 uses banks s[36:41] / s[48:53], cursor 2 uses
+// s[60:65] / s[68:73]; the trip waits ONCE for both cursors' records
+#define NBMI_VISIT_1A \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
+#define NBMI_VISIT_1B \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
+#define NBMI_VISIT_2A \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]")
+#define NBMI_VISIT_2B \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]")
 
 // walks from offset 0 until the cursor reaches `end` (> 0)
 __device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float px, float py, float pz, float eps2,
@@ -592,6 +606,16 @@ __device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float 
                  : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
                    "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
 }
+
+// (defined with the split walk further down)
+__device__ __forceinline__ unsigned seek(const Node *__restrict__ nodes, unsigned S, float px, float py, float pz,
+                                         float eps2, unsigned &resume);
+__device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin, unsigned end, float px, float py,
+                                               float pz, float eps2, unsigned &resume, float &ax, float &ay, float &az);
+__device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
+                                              unsigned end2, float px, float py, float pz, float eps2,
+                                              unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
+                                              float &ax2, float &ay2, float &az2);
 
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
 // otherwise the hand-scheduled loop (eps > 0) or the C++ visit with the distance guard (eps == 0).
@@ -616,7 +640,24 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     unsigned off = 0u;
 
     if (!kCount && !kGuard) {
-        if (nn) walk_asm(nodes, nn, px, py, pz, P.eps2, resume, ax, ay, az);
+        if (nn && P.pair) {
+            // two cursors: [0, mid) and [mid, nn); the second needs the lanes' state at mid (seek)
+            const unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->num_nodes / 2) * kNodeBytes);
+            // (each half sums into its own accumulator, added at the end: a body's result must not depend
+            // on how the two cursors' visits interleave, i.e. on the other bodies of its group)
+            unsigned resume2 = resume;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            unsigned o1 = 0u, o2 = __builtin_amdgcn_readfirstlane(mid ? seek(nodes, mid, px, py, pz, P.eps2, resume2) : 0u);
+            if (mid && o2 < nn)
+                walk_pair_asm(nodes, o1, mid, o2, nn, px, py, pz, P.eps2, resume, resume2, ax, ay, az, bx, by, bz);
+            o1 = __builtin_amdgcn_readfirstlane(o1);
+            o2 = __builtin_amdgcn_readfirstlane(o2);
+            if (o1 < mid) walk_range_asm(nodes, o1, mid, px, py, pz, P.eps2, resume, ax, ay, az);
+            if (o2 < nn && o2 >= mid) walk_range_asm(nodes, o2, nn, px, py, pz, P.eps2, resume2, bx, by, bz);
+            ax += bx; ay += by; az += bz;
+        } else if (nn) {
+            walk_asm(nodes, nn, px, py, pz, P.eps2, resume, ax, ay, az);
+        }
     } else {
         unsigned long long wv = 0, lv = 0, la = 0, jm = 0;
         unsigned long long wm[4] = {0, 0, 0, 0};
@@ -729,6 +770,43 @@ __device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin
                  : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
                  : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
                    "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
+}
+
+// Two cursors in one wave: the same 64 bodies walk [begin1, end1) and [begin2, end2) of the array at
+// once, one visit of each per trip.  A wave issues in order and a scalar load can only be awaited with
+// lgkmcnt(0), so the trip waits once, for both records, and both cursors' next loads are in flight
+// while the other cursor's instructions issue: two dependent load chains per wave instead of one
+// (the hardware holds 8 waves per SIMD; one chain per wave leaves the walk latency-bound at ~73 cycles
+// per visit per SIMD against ~45 of vector issue).  Runs while BOTH cursors are inside their ranges
+// (checked after every trip, so neither oversteps); the caller finishes the longer one alone.
+__device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
+                                              unsigned end2, float px, float py, float pz, float eps2,
+                                              unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
+                                              float &ax2, float &ay2, float &az2) {
+    float dx, dy, dz, d2, inv, f, t;
+    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
+                 "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
+                 "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
+                 "1:\n" NBMI_VISIT_1A NBMI_VISIT_2A
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 2f\n"
+                 "s_cmp_lt_u32 %[off2], %[end2]\n"
+                 "s_cbranch_scc0 2f\n" NBMI_VISIT_1B NBMI_VISIT_2B
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 2f\n"
+                 "s_cmp_lt_u32 %[off2], %[end2]\n"
+                 "s_cbranch_scc1 1b\n"
+                 "2:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : [off] "+s"(off1), [off2] "+s"(off2), [resume] "+v"(resume1), [resume2] "+v"(resume2), [ax] "+v"(ax),
+                   [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2), [ay2] "+v"(ay2), [az2] "+v"(az2), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2),
+                   [inv] "=&v"(inv), [f] "=&v"(f), [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end1),
+                   [end2] "s"(end2)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
+                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s60", "s61", "s62", "s63", "s64",
+                   "s65", "s68", "s69", "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
 }
 
 template <int K>
@@ -1106,6 +1184,7 @@ struct nbmi_sim {
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
+    int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
     // timers
     bool timers = false;
@@ -1227,6 +1306,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
+    P.pair = s->walk_pair;
 
     // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on
     // the size of the tree (not on the shard), so that every sharding adds up the same partial sums.
@@ -1410,6 +1490,7 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
     if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);  // tuning knob (measurement only)
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
+    if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
     if (const char *e = getenv("NBMI_WALK_BLOCK")) {
         const int b = atoi(e);
         if (b == 64 || b == 128 || b == 256) s->walk_block = b;

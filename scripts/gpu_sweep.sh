@@ -1,10 +1,10 @@
 #!/bin/bash
 # Sweep walk tuning knobs with short bench runs (one process per setting).
-# SETTINGS: ';'-separated env assignments, e.g. "NBMI_FETCH=0 NBMI_WALK_CURSORS=1;NBMI_FETCH=1 NBMI_WALK_CURSORS=2"
+# SETTINGS: ';'-separated env assignments, e.g. "NBMI_XCD_CHUNK=0;NBMI_XCD_CHUNK=64;NBMI_WALK_BLOCK=128"
 set -u
 mkdir -p gpurun_out
 : > gpurun_out/sweep.log
-IFS=';' read -ra SETS <<< "${SETTINGS:-NBMI_FETCH=0}"
+IFS=';' read -ra SETS <<< "${SETTINGS:-NBMI_XCD_CHUNK=0}"
 for setting in "${SETS[@]}"; do
   echo "=== $setting" | tee -a gpurun_out/sweep.log
   env $setting timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "

@@ -49,6 +49,45 @@ __global__ __launch_bounds__(256) void k_chase(float *out, const int *__restrict
     }
     out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + (float)s + c;
 }
+// same chain, but the record is fetched through the VECTOR memory path (every lane loads the same
+// address) by all waves (mode 1) or by the odd waves only (mode 2: half scalar, half vector)
+__global__ __launch_bounds__(256) void k_chase_mix(float *out, const int *__restrict__ ring, float a, float b, int mask,
+                                                   int mode) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    const int wave = threadIdx.x >> 6;
+    int c = (blockIdx.x * 4 + wave) & mask;
+    const bool vec = mode == 1 || (mode == 2 && (wave & 1));
+    if (vec) {
+        int cv = c + (threadIdx.x & 0);  // keep it in a VGPR: vector loads
+        for (int i = 0; i < ITER; i++) {
+            cv = ring[cv * 8];
+            asm volatile(V4 S4 V4 S4 V4 S4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s), "+v"(cv) : "v"(a), "v"(b) : "scc");
+        }
+        c = cv;
+    } else {
+        for (int i = 0; i < ITER; i++) {
+            c = __builtin_amdgcn_readfirstlane(c);
+            c = ring[c * 8];
+            asm volatile(V4 S4 V4 S4 V4 S4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + (float)s + c;
+}
+// two / four independent scalar chains per wave (same VALU + SALU work per iteration as k_chase)
+template <int NC>
+__global__ __launch_bounds__(256) void k_chase_n(float *out, const int *__restrict__ ring, float a, float b, int mask) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3; unsigned s = 1;
+    int c[NC];
+    for (int k = 0; k < NC; k++) c[k] = (blockIdx.x * 4 + (threadIdx.x >> 6) + k * 7919) & mask;
+    for (int i = 0; i < ITER; i++) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) { c[k] = __builtin_amdgcn_readfirstlane(c[k]); c[k] = ring[c[k] * 8]; }
+        asm volatile(V4 S4 V4 S4 V4 S4 V4 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(s) : "v"(a), "v"(b) : "scc");
+    }
+    int sum = 0;
+    for (int k = 0; k < NC; k++) sum += c[k];
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + (float)s + sum;
+}
 template <typename F>
 float timeit(F f) {
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
@@ -69,6 +108,18 @@ int main() {
             float t = timeit([&] { k_chase<<<256 * wps, 256>>>(out, ring, 1.0001f, 0.5f, nrec - 1); });
             printf("chase ring %5.1f MB  waves/SIMD %d: %.3f ms  %.1f cyc/iter/SIMD (%.0f cyc/iter/wave) @2.4GHz\n", nrec * 32 / 1048576.0, wps, t,
                    t * 1e-3 * 2.4e9 / ((double)ITER * wps), t * 1e-3 * 2.4e9 / ITER);
+        }
+        {
+            float t2 = timeit([&] { k_chase_n<2><<<256 * 8, 256>>>(out, ring, 1.0001f, 0.5f, nrec - 1); });
+            float t4 = timeit([&] { k_chase_n<4><<<256 * 8, 256>>>(out, ring, 1.0001f, 0.5f, nrec - 1); });
+            printf("chase ring %5.1f MB  8 waves/SIMD  2 chains/wave: %.1f cyc/iter/SIMD   4 chains/wave: %.1f (same VALU/SALU work per iteration)\n",
+                   nrec * 32 / 1048576.0, t2 * 1e-3 * 2.4e9 / ((double)ITER * 8), t4 * 1e-3 * 2.4e9 / ((double)ITER * 8));
+        }
+        for (int mode = 0; mode <= 2; mode++) {
+            float t = timeit([&] { k_chase_mix<<<256 * 8, 256>>>(out, ring, 1.0001f, 0.5f, nrec - 1, mode); });
+            printf("chase ring %5.1f MB  8 waves/SIMD  %s: %.1f cyc/iter/SIMD\n", nrec * 32 / 1048576.0,
+                   mode == 0 ? "scalar loads" : (mode == 1 ? "vector loads" : "half scalar, half vector"),
+                   t * 1e-3 * 2.4e9 / ((double)ITER * 8));
         }
         (void)hipFree(ring); free(h); free(perm);
     }
