@@ -114,6 +114,42 @@ def test_extreme_theta(gpu, oracle, theta):
     sim.close(); one.close()
 
 
+@pytest.mark.parametrize("n,kernel", [(30_000, "split K=16"), (60_000, "split K=8"), (120_000, "split K=4"),
+                                      (250_000, "split K=2"), (320_000, "one wave, two cursors")])
+def test_every_walk_kernel_against_oracle(gpu, oracle, n, kernel):
+    """The product walk picks its kernel by system size: K waves per group over K-ths of the
+    node array below ~280 k bodies, one wave with two cursors above.  One step of each against the oracle,
+    and against the plain one-wave / one-cursor loop (same accepted pairs, sums associated differently)."""
+    import os
+    from tools.presets import generate_distribution
+    np.random.seed(n)
+    p, v, m = generate_distribution("galaxy", n, 500.0, 0.15)
+    m = m * np.random.uniform(0.5, 1.5, n)
+    G, eps, theta, dt = 0.15, 2.0, 0.6, 0.05
+    o = oracle.BHStepper(p, v, m, theta, G, eps, 1.0, cap=oracle.UNCAPPED, fast=False)
+    o.step(dt)
+    sim = _bh(gpu, p, v, m, G, eps, theta=theta)
+    sim.step(dt)
+    os.environ["NBMI_SPLIT_WAVES"] = "0"
+    os.environ["NBMI_WALK_PAIR"] = "0"
+    try:
+        plain = _bh(gpu, p, v, m, G, eps, theta=theta)
+    finally:
+        del os.environ["NBMI_SPLIT_WAVES"], os.environ["NBMI_WALK_PAIR"]
+    plain.step(dt)
+    acc_scale = np.linalg.norm((o.vel - v) / dt, axis=1).max()
+    got, ref, pl = sim.get_positions_f64(), o.pos, plain.get_positions_f64()
+    # position difference after one step = acceleration difference * dt^2
+    err = np.abs(got - ref).max() / (acc_scale * dt * dt)
+    err_plain = np.abs(got - pl).max() / (acc_scale * dt * dt)
+    print(f"{kernel} (n={n}): max acc-equivalent err vs oracle {err:.2e}, vs one-cursor loop {err_plain:.2e}")
+    assert err <= 5e-3            # one opening-test tie (section 5) at most
+    assert np.quantile(np.abs(got - ref).max(axis=1), 0.999) / (acc_scale * dt * dt) <= 2e-5
+    assert err_plain <= 1e-5      # same accepted pairs: only fp32 association differs
+    assert sim.tree_stats()["num_nodes"] == o.num_nodes
+    sim.close(); plain.close()
+
+
 def test_edge_cases(gpu, oracle):
     g = golden("tree_edge_cases")
     for tag in ["n1", "n2", "lattice", "close_pairs", "heavy"]:
