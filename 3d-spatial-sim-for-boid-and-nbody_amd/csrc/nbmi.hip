@@ -536,7 +536,7 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     return any_open ? off + kNodeBytes : nd.next_off;
 }
 
-// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 5 scalar
+// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 4 SALU + 2 SMEM
 // instructions per visit.  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.  The two compares are
 // v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those that TAKE the node,
 // so the force instructions and the `resume` update need no per-lane selects; s_andn2 of the two
