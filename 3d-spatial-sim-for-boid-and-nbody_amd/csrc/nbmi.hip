@@ -777,8 +777,10 @@ __device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin
 // lgkmcnt(0), so the trip waits once, for both records, and both cursors' next loads are in flight
 // while the other cursor's instructions issue: two dependent load chains per wave instead of one
 // (the hardware holds 8 waves per SIMD; one chain per wave leaves the walk latency-bound at ~73 cycles
-// per visit per SIMD against ~45 of vector issue).  Runs while BOTH cursors are inside their ranges
-// (checked after every trip, so neither oversteps); the caller finishes the longer one alone.
+// per visit per SIMD against ~45 of vector issue).  Runs while BOTH cursors are inside their ranges:
+// the first is checked after every trip (it must not step into the second's range), the second after
+// every other trip (its range ends with the self-looping sentinel, one idle visit at worst); the
+// caller finishes the longer one alone.
 __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
                                               unsigned end2, float px, float py, float pz, float eps2,
                                               unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
@@ -790,8 +792,6 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
                  "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
                  "1:\n" NBMI_VISIT_1A NBMI_VISIT_2A
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 2f\n"
-                 "s_cmp_lt_u32 %[off2], %[end2]\n"
                  "s_cbranch_scc0 2f\n" NBMI_VISIT_1B NBMI_VISIT_2B
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc0 2f\n"
