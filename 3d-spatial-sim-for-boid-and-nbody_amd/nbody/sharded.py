@@ -97,7 +97,12 @@ class ShardedBarnesHut:
         self.shared = None
         if dist is not None and hasattr(engine, "share_stream") and dist.get_backend() == "nccl" \
                 and os.environ.get("NBMI_EXCHANGE_SYNC", "0") != "1":
-            self.shared = engine.share_stream()
+            try:
+                self.shared = engine.share_stream()
+            except Exception as ex:  # noqa: BLE001 - keep the host-synchronised exchange rather than fail
+                import sys
+                print(f"[sharded] stream-ordered exchange unavailable ({ex}); synchronising on the host", file=sys.stderr)
+                self.shared = None
 
     def step(self, dt, substeps=1):
         if self.dist is not None and self.shared is not None:
