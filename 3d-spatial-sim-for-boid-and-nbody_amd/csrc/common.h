@@ -22,9 +22,9 @@ void clear_error();
         }                                                                                   \
     } while (0)
 
-// {m, m*x, m*y, m*z} prefix-sum element (float64).
+// {m, m*x, m*y, m*z} prefix-sum element, each a double-double (high word, low word).
 struct Moment {
-    double m, x, y, z;
+    double m, ml, x, xl, y, yl, z, zl;
 };
 
 // ---- sort / scan primitives (sortscan.hip) ---------------------------------------------

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "../../include/nbmi.h"
@@ -67,6 +68,12 @@ struct alignas(8) Node {
     unsigned next_off;  // BYTE offset (index * 24) of the first node after this node's subtree
 };
 constexpr unsigned kNodeBytes = 24;
+// Float64 twin of an internal cell, row = node index: centre of mass and half size as the reference holds
+// them (node_com / node_half_sizes, simulation.py:478-484).  Read only when the fp32 opening test lands
+// inside its uncertainty band (K9); leaves have no row content (a leaf is always accepted).
+struct alignas(16) Node64 {
+    double cx, cy, cz, hs;
+};
 // Node links are 32-bit byte offsets: at most 2^32 / 24 rows.  The reference allocates min(8 M, 4N)
 // rows (simulation.py:477) and uses ~1.5 N; this build allocates 4N + 4096 rows up to that ceiling,
 // which still leaves 1.7 N rows at the largest supported body count.
@@ -93,6 +100,13 @@ struct TreeInfo {
     unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
     unsigned long long jumps;        // cursor moves other than to the next node in memory
     unsigned long long xcd_visits[8];  // counted walk: wave-level visits executed on each XCD
+    unsigned long long band_visits;    // counted walk: lane visits decided by the float64 re-test (near-ties)
+    unsigned band2;                    // width (ulps of d^2) of the opening test's uncertainty band, see K9
+    // Sticky: set together with `error`, but outside the range every step clears.  While it is set the
+    // walk does not advance the state (the bodies keep the last good step), so an overflow in substep 3
+    // of 10 is still there when the host looks (nbmi_sync / getters), which reports and clears it.
+    int sticky_error;
+    long long sticky_nodes;  // num_nodes of the build that overflowed
 };
 
 // ---------------------------------------------------------------------------------------
@@ -189,31 +203,56 @@ __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, c
 }
 
 // ---------------------------------------------------------------------------------------
-// K4: order runs of equal key_hi by key_lo (bodies that share all 21 upper digits; rare).
-// One thread per run start; insertion sort of the run's permutation entries.
+// K4: order runs of equal key_hi by key_lo (bodies that share all 21 upper digits: none at 1 M bodies,
+// pairs at 10 M; thousands inside one level-21 cell once an escaper has inflated the root cube).
+// One thread per body; a body inside a run finds the run's ends by galloping + binary search on the
+// sorted keys and its place by counting the run's members that sort before it - L reads per member,
+// all members in parallel, so a run of 10^5 bodies costs about a millisecond instead of the minutes a
+// one-thread insertion sort would take.  Ties on both words keep the input order (the sort is stable
+// and idx ascends), like the reference's insertion order.  Writes the final permutation to `out`.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
-                                                   uint32_t *__restrict__ perm, int64_t n) {
+                                                   const uint32_t *__restrict__ perm, uint32_t *__restrict__ out, int64_t n) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= n - 1) return;
+    if (r >= n) return;
     const uint64_t h = hi_s[r];
-    if (hi_s[r + 1] != h) return;
-    if (r > 0 && hi_s[r - 1] == h) return;  // not the run start
-    int64_t e = r + 2;
-    while (e < n && hi_s[e] == h) e++;
-    for (int64_t a = r + 1; a < e; a++) {
-        const uint32_t pa = perm[a];
-        const uint64_t la = key_lo[pa];
-        int64_t b = a - 1;
-        while (b >= r) {
-            const uint32_t pb = perm[b];
-            const uint64_t lb = key_lo[pb];
-            if (lb < la || (lb == la && pb < pa)) break;
-            perm[b + 1] = pb;
-            b--;
-        }
-        perm[b + 1] = pa;
+    const uint32_t p = perm[r];
+    const bool tie = (r + 1 < n && hi_s[r + 1] == h) || (r > 0 && hi_s[r - 1] == h);
+    if (!tie) {
+        out[r] = p;
+        return;
     }
+    // run = [s, e): first / one past the last rank with this key_hi
+    int64_t lo_ok = r, lo_bad, step = 1;
+    for (;;) {  // backwards
+        const int64_t t = r - step;
+        if (t < 0) { lo_bad = -1; break; }
+        if (hi_s[t] == h) { lo_ok = t; step <<= 1; } else { lo_bad = t; break; }
+    }
+    while (lo_ok - lo_bad > 1) {
+        const int64_t mid = lo_bad + ((lo_ok - lo_bad) >> 1);
+        if (hi_s[mid] == h) lo_ok = mid; else lo_bad = mid;
+    }
+    int64_t hi_ok = r, hi_bad;
+    step = 1;
+    for (;;) {  // forwards
+        const int64_t t = r + step;
+        if (t >= n) { hi_bad = n; break; }
+        if (hi_s[t] == h) { hi_ok = t; step <<= 1; } else { hi_bad = t; break; }
+    }
+    while (hi_bad - hi_ok > 1) {
+        const int64_t mid = hi_ok + ((hi_bad - hi_ok) >> 1);
+        if (hi_s[mid] == h) hi_ok = mid; else hi_bad = mid;
+    }
+    const int64_t s = lo_ok, e = hi_bad;
+    const uint64_t la = key_lo[p];
+    int64_t before = 0;
+    for (int64_t j = s; j < e; j++) {
+        const uint32_t pj = perm[j];
+        const uint64_t lj = key_lo[pj];
+        before += (lj < la || (lj == la && pj < p)) ? 1 : 0;
+    }
+    out[s + before] = p;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -249,30 +288,68 @@ __global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ h
 // ---------------------------------------------------------------------------------------
 // K7: exclusive prefix sums over the sorted bodies, three hand-written phases (reduce per tile ->
 // scan of the tile sums -> scan inside the tiles).  One pass produces both
-//   S[r]   = sum_{i<r} {G m, G m x, G m y, G m z}   (float64, formed on the fly from posm_s), and
+//   S[r]   = sum_{i<r} {G m, G m x, G m y, G m z}   (double-double, formed on the fly from the float64 state), and
 //   Pex[r] = sum_{i<r} cnt[i]
 // with S[n], Pex[n] = totals.  (rocPRIM's look-back scan of the 32-byte struct ran at ~1 TB/s.)
 // ---------------------------------------------------------------------------------------
 constexpr int kScanItems = 8;                      // elements per thread
 constexpr int kScanTile = kBlock * kScanItems;     // 2048 elements per block
 
+// double-double (unevaluated sum of two float64): the moment sums must give a cell's centre of mass to
+// float64 accuracy however far along the array the cell sits - a plain float64 running sum of 10^6
+// terms loses ~1e-8, which is the size of the opening-test ties the float64 re-decision (K9) exists for.
+struct dd {
+    double h, l;
+};
+__device__ __forceinline__ dd dd_add(const dd &a, const dd &b) {
+    const double s = a.h + b.h;
+    const double bb = s - a.h;
+    double e = (a.h - (s - bb)) + (b.h - bb);
+    e += a.l + b.l;
+    const double h = s + e;
+    return dd{h, e - (h - s)};
+}
+__device__ __forceinline__ dd dd_mul(double a, double b) {
+    const double p = a * b;
+    return dd{p, fma(a, b, -p)};
+}
+__device__ __forceinline__ double dd_diff(const dd &a, const dd &b) {  // a - b, rounded once
+    const dd d = dd_add(a, dd{-b.h, -b.l});
+    return d.h + d.l;
+}
+
 struct ScanVal {
-    double m, x, y, z;
+    dd m, x, y, z;
     int c;
 };
-__device__ __forceinline__ ScanVal sv_zero() { return ScanVal{0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ ScanVal sv_zero() { return ScanVal{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, 0}; }
 __device__ __forceinline__ ScanVal sv_add(const ScanVal &a, const ScanVal &b) {
-    return ScanVal{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z, a.c + b.c};
+    return ScanVal{dd_add(a.m, b.m), dd_add(a.x, b.x), dd_add(a.y, b.y), dd_add(a.z, b.z), a.c + b.c};
 }
-__device__ __forceinline__ ScanVal sv_load(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
-                                           int64_t i, int64_t n) {
+// Where the sorted bodies' moments come from: the handle's own float64 state through the sort
+// permutation (single GPU and row-exchange shards), or fp32 records received from other ranks (run exchange).
+struct MomentSrc {
+    Bodies cur;                 // float64 state (perm != nullptr)
+    const uint32_t *perm;
+    const float4 *posm;         // fallback: fp32 {x,y,z,G m}
+    double G;
+};
+__device__ __forceinline__ ScanVal sv_load(const MomentSrc &src, const int32_t *__restrict__ cnt, int64_t i, int64_t n) {
     if (i >= n) return sv_zero();
-    const float4 p = posm_s[i];
-    const double gm = (double)p.w;
-    return ScanVal{gm, gm * (double)p.x, gm * (double)p.y, gm * (double)p.z, cnt[i]};
+    double gm, x, y, z;
+    if (src.perm) {
+        const uint32_t j = src.perm[i];
+        gm = src.G * src.cur.m[j];
+        x = src.cur.x[j]; y = src.cur.y[j]; z = src.cur.z[j];
+    } else {
+        const float4 p = src.posm[i];
+        gm = (double)p.w; x = (double)p.x; y = (double)p.y; z = (double)p.z;
+    }
+    return ScanVal{{gm, 0.0}, dd_mul(gm, x), dd_mul(gm, y), dd_mul(gm, z), cnt[i]};
 }
+__device__ __forceinline__ dd dd_shfl_up(const dd &v, int d) { return dd{__shfl_up(v.h, d), __shfl_up(v.l, d)}; }
 __device__ __forceinline__ ScanVal sv_shfl_up(const ScanVal &v, int d) {
-    return ScanVal{__shfl_up(v.m, d), __shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.c, d)};
+    return ScanVal{dd_shfl_up(v.m, d), dd_shfl_up(v.x, d), dd_shfl_up(v.y, d), dd_shfl_up(v.z, d), __shfl_up(v.c, d)};
 }
 // inclusive scan across the 256 threads of a block; returns the thread's inclusive value and the
 // block total in `total`
@@ -296,14 +373,14 @@ __device__ __forceinline__ ScanVal block_inclusive_scan(ScanVal v, ScanVal *lds 
     return sv_add(off, v);
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(MomentSrc src, const int32_t *__restrict__ cnt,
                                                         int64_t n, ScanVal *__restrict__ tile_sum) {
     __shared__ ScanVal lds[kBlock / 64];
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
     ScanVal acc = sv_zero();
 #pragma unroll
     for (int k = 0; k < kScanItems; k++)  // strided: coalesced loads
-        acc = sv_add(acc, sv_load(posm_s, cnt, base + (int64_t)k * kBlock + threadIdx.x, n));
+        acc = sv_add(acc, sv_load(src, cnt, base + (int64_t)k * kBlock + threadIdx.x, n));
     ScanVal total;
     (void)block_inclusive_scan(acc, lds, total);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
@@ -334,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_tiles(ScanVal *__restrict__ til
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_apply(const float4 *__restrict__ posm_s, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void k_scan_apply(MomentSrc src, const int32_t *__restrict__ cnt,
                                                        int64_t n, const ScanVal *__restrict__ tile_off,
                                                        Moment *__restrict__ S, int32_t *__restrict__ Pex) {
     __shared__ ScanVal lds[kBlock / 64];
@@ -345,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const float4 *__restrict_
     ScanVal sum = sv_zero();
 #pragma unroll
     for (int k = 0; k < kScanItems; k++) {
-        v[k] = sv_load(posm_s, cnt, base + k, n);
+        v[k] = sv_load(src, cnt, base + k, n);
         sum = sv_add(sum, v[k]);
     }
     ScanVal total;
@@ -355,11 +432,20 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const float4 *__restrict_
     for (int k = 0; k < kScanItems; k++) {
         const int64_t i = base + k;
         if (i <= n) {  // entry n receives the grand totals
-            S[i] = Moment{run.m, run.x, run.y, run.z};
+            S[i] = Moment{run.m.h, run.m.l, run.x.h, run.x.l, run.y.h, run.y.l, run.z.h, run.z.l};
             Pex[i] = run.c;
         }
         run = sv_add(run, v[k]);
     }
+}
+
+// Half width K (ulps of d^2, a power of two) of the opening test's uncertainty band; derivation at K9.
+__device__ __forceinline__ unsigned band_half_ulps(double bounds, double eps) {
+    double k = 16.0 + 8.0 * bounds / eps;  // eps == 0: inf
+    if (!(k < 2097152.0)) k = 2097152.0;   // cap 2^21 (band 2^22 ulps = a factor 1.5 ... 2 in d^2)
+    unsigned K = 16u;
+    while ((double)K < k) K <<= 1;
+    return K;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -376,13 +462,22 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
                                                         const float4 *__restrict__ posm_s, int64_t n, int64_t capacity,
                                                         Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
                                                         int32_t *__restrict__ node_ref, int32_t *__restrict__ cell_r,
-                                                        uint8_t *__restrict__ cell_lev, TreeInfo *info) {
+                                                        uint8_t *__restrict__ cell_lev, double eps, TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r < n) {
         const int64_t total = n + (int64_t)Pex[n];
-        if (r == 0) info->num_nodes = total;
+        if (r == 0) {
+            info->num_nodes = total;
+            info->band2 = 2u * band_half_ulps(info->bounds, eps);
+        }
         if (total + 1 > capacity) {  // + 1: the sentinel
-            if (r == 0) info->error = 1;
+            if (r == 0) {
+                info->error = 1;
+                if (info->sticky_error == 0) {
+                    info->sticky_error = 1;
+                    info->sticky_nodes = total;
+                }
+            }
         } else {
             const int d = delta[r];
             const int dp = r > 0 ? delta[r - 1] : -1;
@@ -439,8 +534,9 @@ __global__ __launch_bounds__(kBlock) void k_max_level(const int32_t *__restrict_
 __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
                                                        const int32_t *__restrict__ Pex, const Moment *__restrict__ S,
                                                        const int32_t *__restrict__ cell_r, const uint8_t *__restrict__ cell_lev,
-                                                       int64_t n, double G, double inv_theta2, int64_t capacity,
-                                                       Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
+                                                       int64_t n, double eps, double inv_theta2, int64_t capacity,
+                                                       Node *__restrict__ nodes, Node64 *__restrict__ nodes64,
+                                                       uint8_t *__restrict__ node_level,
                                                        int32_t *__restrict__ node_ref, const TreeInfo *__restrict__ info) {
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t ncells = Pex[n];
@@ -463,21 +559,25 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
     }
     const int64_t e = bad;
     const Moment s0 = S[r], s1 = S[e];
-    const double M = s1.m - s0.m;
+    const double M = dd_diff(dd{s1.m, s1.ml}, dd{s0.m, s0.ml});
     double cx = 0.0, cy = 0.0, cz = 0.0;
     if (M > 0.0) {
-        cx = (s1.x - s0.x) / M;
-        cy = (s1.y - s0.y) / M;
-        cz = (s1.z - s0.z) / M;
+        cx = dd_diff(dd{s1.x, s1.xl}, dd{s0.x, s0.xl}) / M;
+        cy = dd_diff(dd{s1.y, s1.yl}, dd{s0.y, s0.yl}) / M;
+        cz = dd_diff(dd{s1.z, s1.zl}, dd{s0.z, s0.zl}) / M;
     }
-    const double size = ldexp(info->bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
+    const double bounds = info->bounds;
+    const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
     const int64_t idx = r + q;
     Node nd;
     nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
     nd.gm = (float)M;  // the moments are sums of G*m
-    nd.s2t = (float)(size * size * inv_theta2);
+    // upper edge of the uncertainty band: bits((2 hs)^2 / theta^2) + K  (theta == 0: +inf, never accepted)
+    const float s2t = (float)(size * size * inv_theta2);
+    nd.s2t = __int_as_float(__float_as_int(s2t) + (int)band_half_ulps(bounds, eps));
     nd.next_off = (unsigned)(e + (int64_t)Pex[e]) * kNodeBytes;
     nodes[idx] = nd;
+    nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
     node_ref[idx] = (int32_t)r;
     node_level[idx] = (uint8_t)lev;
 }
@@ -495,6 +595,19 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 // everything before that).  The cursor moves to the next node in memory if any lane opens the node, else to
 // next_off.  Fused epilogue: v = (v + a dt) * damping; x += v dt  (simulation.py:291-305),
 // written at the body's NEW sorted rank (state re-ordering is fused into this kernel).
+//
+// Opening-test ties.  The test runs in fp32 on fp32-rounded positions, the reference's in float64; a
+// (body, node) pair whose d^2 lies within the rounding error of the threshold can be decided the other
+// way, and such a body then carries a different (equally legitimate) Barnes-Hut approximation - enough
+// to miss the 1e-4 position bound after 100 steps at 1 M bodies.  So the node stores the UPPER edge of
+// an uncertainty band, bits(s2t) + K, the walk derives the lower edge bits(s2t) - K, and a lane whose
+// d^2 falls between the two is re-decided exactly as the reference does it (simulation.py:252-258):
+// float64 body position, float64 centre of mass (double-double prefix sums, see k_scan_*), sqrt and
+// divide.  K (ulps of d^2) bounds the fp32 error: both positions are rounded by <= 2^-24 maxabs, so
+// d^2 is off by <= 2 sqrt(3) d 2^-23 maxabs + a few ulps; the test only matters where d >= eps
+// (smaller cells pass it through eps^2 alone), hence K = 16 + 8 bounds / eps, rounded up to a power of
+// two (TreeInfo.band2 = 2 K).  One extra compare per visit; the float64 path runs for ~1e-4 of the
+// lane visits.
 // ---------------------------------------------------------------------------------------
 struct WalkParams {
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
@@ -503,26 +616,59 @@ struct WalkParams {
     int xcd_chunk;  // see logical_block()
     int pair;       // one-wave walk with two cursors (the two halves of the array)
     double dt, damping;
+    int curbuf;  // which of WalkTable.buf holds the current state
 };
 
-// One node visit (C++ form; the counted / eps == 0 kernels use it).  `off` is the cursor as a byte
-// offset into the node array; `resume` likewise.  Returns the next cursor.
+// Per-handle constants the walk needs only rarely (float64 re-decision) or only at its end (the state
+// pointers of the fused kick-drift).  They live in device memory, not in kernel arguments: arguments sit
+// in SGPRs for the whole kernel, and with 16 state pointers among them the walk needed 92 SGPRs - over
+// the 80 at which the hardware still admits eight 256-thread blocks per CU.
+struct WalkTable {
+    Bodies buf[2];
+    const Node64 *n64;
+    double theta, eps2;
+};
+
+// where a lane finds its body's float64 position (only read on the re-decision path)
+struct Body64 {
+    const WalkTable *tab;
+    int curbuf;
+    uint32_t j;
+};
+
+// the reference's own test in float64 (simulation.py:249-258), operation for operation
+__device__ __forceinline__ bool exact_take(unsigned off, const Body64 &b) {
+    const WalkTable *t = b.tab;
+    const Node64 c = t->n64[off / kNodeBytes];
+    const Bodies &cur = t->buf[b.curbuf];
+    const double dx = c.cx - cur.x[b.j], dy = c.cy - cur.y[b.j], dz = c.cz - cur.z[b.j];
+    const double dist_sq = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)), t->eps2);
+    const double dist = sqrt(dist_sq);
+    return (c.hs * 2.0) / dist < t->theta;
+}
+
+// One node visit (C++ form: counted / eps == 0 kernels, seek(), and the product walk's re-decision visits).
+// `off` is the cursor as a byte offset into the node array; `resume` likewise.  Returns the next cursor.
 template <bool kGuard>
-__device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsigned off, float px, float py, float pz,
-                                          float eps2, unsigned &resume, float &ax, float &ay, float &az,
-                                          bool &active_out, bool &force_out, bool &jumped) {
+__device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsigned off,
+                                          float px, float py, float pz, const Body64 &b64, const WalkParams &P,
+                                          unsigned band2, unsigned &resume, float &ax, float &ay, float &az,
+                                          bool &active_out, bool &force_out, bool &jumped, bool &band_out) {
     off = __builtin_amdgcn_readfirstlane(off);
     const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
     const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
-    const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
+    const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
     const bool active = resume <= off;
-    // both operands are non-negative floats: compare their bit patterns as integers
-    const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
+    // non-negative floats: compare bit patterns as integers.  hi / lo = edges of the uncertainty band.
+    const int d2b = __float_as_int(dist_sq), hi = __float_as_int(nd.s2t), lo = hi - (int)band2;
+    bool geom = hi < d2b;
+    const bool band = active && !geom && lo < d2b;
+    if (band) geom = (hi == 0) || exact_take(off, b64);  // rare, divergent
     const unsigned long long m_active = __builtin_amdgcn_ballot_w64(active);
     const unsigned long long m_geom = __builtin_amdgcn_ballot_w64(geom);
     const bool take = active && geom;
     bool force = take;
-    if (kGuard) force = take && (dist_sq > eps2);
+    if (kGuard) force = take && (dist_sq > P.eps2);
     const float inv = __builtin_amdgcn_rsqf(dist_sq);
     const float f = force ? nd.gm * inv * inv * inv : 0.f;
     ax = fmaf(dx, f, ax);
@@ -531,13 +677,14 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     resume = take ? nd.next_off : resume;
     const unsigned long long any_open = m_active & ~m_geom;
     active_out = active;
-    force_out = take && (dist_sq > eps2);
+    force_out = take && (dist_sq > P.eps2);
+    band_out = band;
     jumped = !any_open && nd.next_off != off + kNodeBytes;
     return any_open ? off + kNodeBytes : nd.next_off;
 }
 
-// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 4 SALU + 2 SMEM
-// instructions per visit.  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.  The two compares are
+// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 17 VALU + 6 SALU + 2 SMEM
+// instructions per visit.  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.  The two deciding compares are
 // v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those that TAKE the node,
 // so the force instructions and the `resume` update need no per-lane selects; s_andn2 of the two
 // masks leaves "some lane opens" in SCC for the s_cselect that picks off + 24 / next_off; EXEC is
@@ -548,17 +695,24 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 // takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
 // asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
 // a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
-#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI) \
+// Near-tie exit: one extra v_cmp against the lower band edge (s54 = s2t - band2); if a taking-part lane
+// lies inside the band the loop is left BEFORE this visit changes anything (cursor, resume, sums), the
+// caller performs that one visit in C++ with the float64 test and re-enters.
+#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI, EXITL) \
     "v_cmpx_ge_u32_e64 s[44:45], " OFF ", " RES "\n"           \
     "s_add_u32 s58, " OFF ", 24\n"                             \
     WAIT                                                       \
+    "s_sub_u32 s54, " S2T ", %[band2]\n"                       \
     "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
     "v_sub_f32_e32 %[dy], " CY ", %[py]\n"                     \
     "v_sub_f32_e32 %[dz], " CZ ", %[pz]\n"                     \
     "v_fma_f32 %[d2], %[dx], %[dx], %[eps2]\n"                 \
     "v_fmac_f32_e32 %[d2], %[dy], %[dy]\n"                     \
     "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
+    "v_cmp_lt_i32_e64 s[42:43], s54, %[d2]\n"                  \
     "v_cmpx_lt_i32_e64 s[46:47], " S2T ", %[d2]\n"             \
+    "s_andn2_b64 s[42:43], s[42:43], s[46:47]\n"               \
+    "s_cbranch_scc1 " EXITL "\n"                               \
     "s_andn2_b64 s[56:57], s[44:45], s[46:47]\n"               \
     "s_cselect_b32 " OFF ", s58, " NXT "\n"                    \
     "s_load_dwordx4 " NEXTLO ", %[base], " OFF "\n"            \
@@ -574,70 +728,215 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "s_mov_b64 exec, -1\n"
 #define NBMI_WAIT "s_waitcnt lgkmcnt(0)\n"
 #define NBMI_VISIT_A \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]", "7f")
 #define NBMI_VISIT_B \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]", "7f")
 // two cursors in one wave (walk_pair_asm): cursor 1 uses banks s[36:41] / s[48:53], cursor 2 uses
 // s[60:65] / s[68:73]; the trip waits ONCE for both cursors' records
-#define NBMI_VISIT_1A \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]")
-#define NBMI_VISIT_1B \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]")
+#define NBMI_VISIT_1A NBMI_VISIT_A
+#define NBMI_VISIT_1B NBMI_VISIT_B
 #define NBMI_VISIT_2A \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]")
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]", "8f")
 #define NBMI_VISIT_2B \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]")
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", "8f")
+// leaving the loop on a near-tie: all lanes back on, tell the caller which cursor stopped
+#define NBMI_EXITS                      \
+    "s_branch 9f\n"                     \
+    "7:\n"                              \
+    "s_mov_b64 exec, -1\n"              \
+    "s_mov_b32 %[which], 1\n"           \
+    "s_branch 9f\n"                     \
+    "8:\n"                              \
+    "s_mov_b64 exec, -1\n"              \
+    "s_mov_b32 %[which], 2\n"           \
+    "9:\n"                              \
+    "s_waitcnt lgkmcnt(0)\n"
+#define NBMI_CLOBBERS                                                                                               \
+    "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+        "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory"
 
-// walks from offset 0 until the cursor reaches `end` (> 0)
-__device__ __forceinline__ void walk_asm(const Node *nodes, unsigned end, float px, float py, float pz, float eps2,
-                                         unsigned &resume, float &ax, float &ay, float &az) {
+// walks from `off` until the cursor reaches `end` (the end of the array: 4 visits per loop test, the
+// sentinel absorbs the overshoot) or a near-tie stops it (which = 1, cursor on the tied node)
+__device__ __forceinline__ void walk4_asm(const Node *nodes, unsigned &off, unsigned end, float px, float py, float pz,
+                                          float eps2, unsigned band2, unsigned &resume, float &ax, float &ay, float &az,
+                                          unsigned &which) {
     float dx, dy, dz, d2, inv, f, t;
-    unsigned off = 0u;
     asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n"
-                 "s_waitcnt lgkmcnt(0)\n"
-                 : [off] "+s"(off), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az),
-                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv), [f] "=&v"(f),
-                   [t] "=&v"(t)
-                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
-                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
-                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
+                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
+                   [az] "+v"(az), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
+                   [f] "=&v"(f), [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end),
+                   [band2] "s"(band2)
+                 : NBMI_CLOBBERS);
 }
 
-// (defined with the split walk further down)
-__device__ __forceinline__ unsigned seek(const Node *__restrict__ nodes, unsigned S, float px, float py, float pz,
-                                         float eps2, unsigned &resume);
-__device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin, unsigned end, float px, float py,
-                                               float pz, float eps2, unsigned &resume, float &ax, float &ay, float &az);
+// one visit per loop test: a part must not step past its end (the next part starts there)
+__device__ __forceinline__ void walk1_asm(const Node *nodes, unsigned &off, unsigned end, float px, float py, float pz,
+                                          float eps2, unsigned band2, unsigned &resume, float &ax, float &ay, float &az,
+                                          unsigned &which) {
+    float dx, dy, dz, d2, inv, f, t;
+    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
+                 "1:\n" NBMI_VISIT_A
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
+                   [az] "+v"(az), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
+                   [f] "=&v"(f), [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end),
+                   [band2] "s"(band2)
+                 : NBMI_CLOBBERS);
+}
+
+// Two cursors in one wave: the same 64 bodies walk [off1, end1) and [off2, end2) of the array at
+// once, one visit of each per trip.  A wave issues in order and a scalar load can only be awaited with
+// lgkmcnt(0), so the trip waits once, for both records, and both cursors' next loads are in flight
+// while the other cursor's instructions issue: two dependent load chains per wave instead of one.
+// Runs while BOTH cursors are inside their ranges: the first is checked after every trip (it must not
+// step into the second's range), the second after every other trip (its range ends with the
+// self-looping sentinel, one idle visit at worst); the caller finishes the longer one alone.
 __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
-                                              unsigned end2, float px, float py, float pz, float eps2,
+                                              unsigned end2, float px, float py, float pz, float eps2, unsigned band2,
                                               unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
-                                              float &ax2, float &ay2, float &az2);
+                                              float &ax2, float &ay2, float &az2, unsigned &which) {
+    float dx, dy, dz, d2, inv, f, t;
+    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
+                 "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
+                 "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
+                 "1:\n" NBMI_VISIT_1A NBMI_VISIT_2A
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_1B NBMI_VISIT_2B
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 9f\n"
+                 "s_cmp_lt_u32 %[off2], %[end2]\n"
+                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 : [off] "+s"(off1), [off2] "+s"(off2), [which] "+s"(which), [resume] "+v"(resume1),
+                   [resume2] "+v"(resume2), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2),
+                   [ay2] "+v"(ay2), [az2] "+v"(az2), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2),
+                   [inv] "=&v"(inv), [f] "=&v"(f), [t] "=&v"(t)
+                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end1),
+                   [end2] "s"(end2), [band2] "s"(band2)
+                 : NBMI_CLOBBERS, "s60", "s61", "s62", "s63", "s64", "s65", "s68", "s69", "s70", "s71", "s72", "s73");
+}
+
+// everything a lane carries through a walk
+struct WalkCtx {
+    const Node *nodes;
+    float px, py, pz;
+    Body64 b64;
+    unsigned band2;
+};
+
+// one visit with the float64 re-decision (the asm loop stopped on this node)
+__device__ __forceinline__ unsigned tie_visit(const WalkCtx &C, const WalkParams &P, unsigned off, unsigned &resume,
+                                              float &ax, float &ay, float &az) {
+    bool a_, f_, j_, b_;
+    return __builtin_amdgcn_readfirstlane(
+        visit<false>(C.nodes, off, C.px, C.py, C.pz, C.b64, P, C.band2, resume, ax, ay, az, a_, f_, j_, b_));
+}
+
+// the cursor `off` walks until it reaches `end`; kToEnd: `end` is the end of the array (unrolled loop)
+template <bool kToEnd>
+__device__ __forceinline__ void walk_span(const WalkCtx &C, const WalkParams &P, unsigned off, unsigned end,
+                                          unsigned &resume, float &ax, float &ay, float &az) {
+    off = __builtin_amdgcn_readfirstlane(off);
+    while (off < end) {
+        unsigned which = 0u;
+        if (kToEnd) walk4_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, which);
+        else walk1_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, which);
+        off = __builtin_amdgcn_readfirstlane(off);
+        if (!__builtin_amdgcn_readfirstlane(which)) break;
+        off = tie_visit(C, P, off, resume, ax, ay, az);
+    }
+}
+
+// Split / pair walks start a cursor in the middle of the array, at offset S.  The lane's `resume` there
+// is what the full walk would have left: only the ancestors of S can have set it beyond S, so seek()
+// replays the opening test down that chain (no forces: an ancestor lies before S and belongs to
+// another part).  Returns the first offset >= S the walk visits.
+__device__ __forceinline__ unsigned seek(const WalkCtx &C, const WalkParams &P, unsigned S, unsigned &resume) {
+    unsigned off = 0u;
+    while (off < S) {
+        off = __builtin_amdgcn_readfirstlane(off);
+        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(C.nodes) + off);
+        const float dx = nd.cx - C.px, dy = nd.cy - C.py, dz = nd.cz - C.pz;
+        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
+        const bool active = resume <= off;
+        const int d2b = __float_as_int(dist_sq), hi = __float_as_int(nd.s2t), lo = hi - (int)C.band2;
+        bool geom = hi < d2b;
+        if (active && !geom && lo < d2b) geom = (hi == 0) || exact_take(off, C.b64);
+        if (active && geom) resume = nd.next_off;
+        if (__builtin_amdgcn_ballot_w64(active && !geom) == 0ull) {
+            off = nd.next_off;  // nobody opens this ancestor: the walk never enters it
+            continue;
+        }
+        // descend to the child whose subtree contains S
+        unsigned c = off + kNodeBytes;
+        for (;;) {
+            c = __builtin_amdgcn_readfirstlane(c);
+            const unsigned nxt = reinterpret_cast<const Node *>(reinterpret_cast<const char *>(C.nodes) + c)->next_off;
+            if (nxt > S) break;
+            c = nxt;
+        }
+        off = c;
+    }
+    return off;
+}
+
+// fused kick-drift (simulation.py:291-305) of the body at sorted rank `rank`, written at that rank of the
+// other buffer; frozen (a capacity error is pending): the body moves to its rank unchanged
+__device__ __forceinline__ void integrate(const WalkTable *tab, uint32_t j, int64_t rank, float ax,
+                                          float ay, float az, const WalkParams &P, bool frozen) {
+    const Bodies cur = tab->buf[P.curbuf], nxt = tab->buf[1 - P.curbuf];
+    double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
+    double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j];
+    const double m0 = cur.m[j];
+    const int32_t id0 = cur.id[j];
+    if (!frozen) {
+        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
+        vx *= P.damping; vy *= P.damping; vz *= P.damping;
+        x0 += vx * P.dt; y0 += vy * P.dt; z0 += vz * P.dt;
+    }
+    nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
+    nxt.x[rank] = x0; nxt.y[rank] = y0; nxt.z[rank] = z0;
+    nxt.m[rank] = m0;
+    nxt.id[rank] = id0;
+}
 
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
 // otherwise the hand-scheduled loop (eps > 0) or the C++ visit with the distance guard (eps == 0).
 template <bool kIntegrate, bool kCount, bool kGuard>
-__global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const TreeInfo *info_in,
-                                                 const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
-                                                 Bodies cur, Bodies nxt, double *__restrict__ acc_out, WalkParams P,
-                                                 TreeInfo *info_out) {
+__global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes, const WalkTable *tab,
+                                                 const TreeInfo *info_in, const float4 *__restrict__ posm_s,
+                                                 const uint32_t *__restrict__ perm,
+                                                 double *__restrict__ acc_out, WalkParams P, TreeInfo *info_out) {
     const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
     const int lane = threadIdx.x & 63;
     const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
     const bool valid = rank < P.rank_end;
-    const unsigned nn = (info_in->error != 0) ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);  // end offset
+    const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
+    const unsigned nn = frozen ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);  // end offset
 
-    float px = 0.f, py = 0.f, pz = 0.f;
+    WalkCtx C;
+    C.nodes = nodes;
+    C.px = C.py = C.pz = 0.f;
+    C.band2 = __builtin_amdgcn_readfirstlane(info_in->band2);
+    uint32_t j = 0;
     if (valid) {
         const float4 p = posm_s[rank];
-        px = p.x; py = p.y; pz = p.z;
+        C.px = p.x; C.py = p.y; C.pz = p.z;
+        j = perm[rank];
     }
+    C.b64 = Body64{tab, P.curbuf, j};
     unsigned resume = valid ? 0u : 0xffffffffu;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    unsigned off = 0u;
 
     if (!kCount && !kGuard) {
         if (nn && P.pair) {
@@ -647,27 +946,35 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
             // on how the two cursors' visits interleave, i.e. on the other bodies of its group)
             unsigned resume2 = resume;
             float bx = 0.f, by = 0.f, bz = 0.f;
-            unsigned o1 = 0u, o2 = __builtin_amdgcn_readfirstlane(mid ? seek(nodes, mid, px, py, pz, P.eps2, resume2) : 0u);
-            if (mid && o2 < nn)
-                walk_pair_asm(nodes, o1, mid, o2, nn, px, py, pz, P.eps2, resume, resume2, ax, ay, az, bx, by, bz);
-            o1 = __builtin_amdgcn_readfirstlane(o1);
-            o2 = __builtin_amdgcn_readfirstlane(o2);
-            if (o1 < mid) walk_range_asm(nodes, o1, mid, px, py, pz, P.eps2, resume, ax, ay, az);
-            if (o2 < nn && o2 >= mid) walk_range_asm(nodes, o2, nn, px, py, pz, P.eps2, resume2, bx, by, bz);
+            unsigned o1 = 0u, o2 = __builtin_amdgcn_readfirstlane(mid ? seek(C, P, mid, resume2) : 0u);
+            while (mid && o1 < mid && o2 < nn) {
+                unsigned which = 0u;
+                walk_pair_asm(nodes, o1, mid, o2, nn, C.px, C.py, C.pz, P.eps2, C.band2, resume, resume2, ax, ay, az,
+                              bx, by, bz, which);
+                o1 = __builtin_amdgcn_readfirstlane(o1);
+                o2 = __builtin_amdgcn_readfirstlane(o2);
+                which = __builtin_amdgcn_readfirstlane(which);
+                if (which == 1u) o1 = tie_visit(C, P, o1, resume, ax, ay, az);
+                else if (which == 2u) o2 = tie_visit(C, P, o2, resume2, bx, by, bz);
+                else break;
+            }
+            if (o1 < mid) walk_span<false>(C, P, o1, mid, resume, ax, ay, az);
+            if (o2 < nn && o2 >= mid) walk_span<true>(C, P, o2, nn, resume2, bx, by, bz);
             ax += bx; ay += by; az += bz;
         } else if (nn) {
-            walk_asm(nodes, nn, px, py, pz, P.eps2, resume, ax, ay, az);
+            walk_span<true>(C, P, 0u, nn, resume, ax, ay, az);
         }
     } else {
-        unsigned long long wv = 0, lv = 0, la = 0, jm = 0;
+        unsigned long long wv = 0, lv = 0, la = 0, jm = 0, bd = 0;
         unsigned long long wm[4] = {0, 0, 0, 0};
         int wbase[4] = {-1000, -1000, -1000, -1000};
+        unsigned off = 0u;
         while (off < nn) {
-            bool a_, f_, j_;
+            bool a_, f_, j_, b_;
             const int c_old = (int)(off / kNodeBytes);
-            off = visit<kGuard>(nodes, off, px, py, pz, P.eps2, resume, ax, ay, az, a_, f_, j_);
+            off = visit<kGuard>(nodes, off, C.px, C.py, C.pz, C.b64, P, C.band2, resume, ax, ay, az, a_, f_, j_, b_);
             if (kCount) {
-                wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0;
+                wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0; bd += b_ ? 1 : 0;
 #pragma unroll
                 for (int w = 0; w < 4; w++) {
                     if (c_old < wbase[w] || c_old >= wbase[w] + (8 << w)) { wm[w]++; wbase[w] = c_old; }
@@ -685,24 +992,14 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
             }
             atomicAdd(&info_out->lane_visits, lv);
             atomicAdd(&info_out->lane_accepts, la);
+            if (bd) atomicAdd(&info_out->band_visits, bd);
         }
     }
     if (!valid) return;
-    const uint32_t j = perm[rank];
     if (kIntegrate) {
-        double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
-        const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
-        const int32_t id0 = cur.id[j];
-        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
-        vx *= P.damping; vy *= P.damping; vz *= P.damping;
-        nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
-        nxt.x[rank] = x0 + vx * P.dt;
-        nxt.y[rank] = y0 + vy * P.dt;
-        nxt.z[rank] = z0 + vz * P.dt;
-        nxt.m[rank] = m0;
-        nxt.id[rank] = id0;
+        integrate(tab, j, rank, ax, ay, az, P, frozen);
     } else {
-        const int64_t o = 3 * (int64_t)cur.id[j];
+        const int64_t o = 3 * (int64_t)tab->buf[P.curbuf].id[j];
         acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
     }
 }
@@ -715,125 +1012,42 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
 // (Measured at 100 k bodies, K = 4: equal quarters 0.179 ms; quarters centred on the group's own
 // leaves with a near range of 1/8 ... 1/8192 of the array 0.204 ... 0.257 ms - a galaxy's far field
 // is where most visits are, so plain equal parts balance best, and they do not depend on the
-// group.)  A part that starts at S needs every lane's `resume` as the full walk would have it
-// there: only the ancestors of S can have set it beyond S, so seek() replays the opening test down
-// that chain (no forces: an ancestor lies before S and belongs to another part).  The K partial
+// group.)  A part that starts at S gets its lanes' `resume` from seek().  The K partial
 // sums meet in LDS and are added in fixed order, then the usual fused kick-drift.  Same accepted
 // (body, node) set as the one-wave walk; the fp32 sums associate differently (by fixed node ranges,
 // so a body's result still does not depend on its group or on the sharding).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned seek(const Node *__restrict__ nodes, unsigned S, float px, float py, float pz,
-                                         float eps2, unsigned &resume) {
-    unsigned off = 0u;
-    while (off < S) {
-        off = __builtin_amdgcn_readfirstlane(off);
-        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
-        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
-        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
-        const bool active = resume <= off;
-        const bool geom = __float_as_int(nd.s2t) < __float_as_int(dist_sq);
-        if (active && geom) resume = nd.next_off;
-        if (__builtin_amdgcn_ballot_w64(active && !geom) == 0ull) {
-            off = nd.next_off;  // nobody opens this ancestor: the walk never enters it
-            continue;
-        }
-        // descend to the child whose subtree contains S
-        unsigned c = off + kNodeBytes;
-        for (;;) {
-            c = __builtin_amdgcn_readfirstlane(c);
-            const unsigned nxt = reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + c)->next_off;
-            if (nxt > S) break;
-            c = nxt;
-        }
-        off = c;
-    }
-    return off;
-}
-
-// one visit per loop test: a part must not step past its end (the next part starts there)
-__device__ __forceinline__ void walk_range_asm(const Node *nodes, unsigned begin, unsigned end, float px, float py,
-                                               float pz, float eps2, unsigned &resume, float &ax, float &ay, float &az) {
-    float dx, dy, dz, d2, inv, f, t;
-    unsigned off = begin;
-    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
-                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A
-                 "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 2f\n" NBMI_VISIT_B
-                 "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n"
-                 "2:\n"
-                 "s_waitcnt lgkmcnt(0)\n"
-                 : [off] "+s"(off), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az),
-                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv), [f] "=&v"(f),
-                   [t] "=&v"(t)
-                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end)
-                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
-                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "vcc", "scc", "memory");
-}
-
-// Two cursors in one wave: the same 64 bodies walk [begin1, end1) and [begin2, end2) of the array at
-// once, one visit of each per trip.  A wave issues in order and a scalar load can only be awaited with
-// lgkmcnt(0), so the trip waits once, for both records, and both cursors' next loads are in flight
-// while the other cursor's instructions issue: two dependent load chains per wave instead of one
-// (the hardware holds 8 waves per SIMD; one chain per wave leaves the walk latency-bound at ~73 cycles
-// per visit per SIMD against ~45 of vector issue).  Runs while BOTH cursors are inside their ranges:
-// the first is checked after every trip (it must not step into the second's range), the second after
-// every other trip (its range ends with the self-looping sentinel, one idle visit at worst); the
-// caller finishes the longer one alone.
-__device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
-                                              unsigned end2, float px, float py, float pz, float eps2,
-                                              unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
-                                              float &ax2, float &ay2, float &az2) {
-    float dx, dy, dz, d2, inv, f, t;
-    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
-                 "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
-                 "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
-                 "1:\n" NBMI_VISIT_1A NBMI_VISIT_2A
-                 "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 2f\n" NBMI_VISIT_1B NBMI_VISIT_2B
-                 "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 2f\n"
-                 "s_cmp_lt_u32 %[off2], %[end2]\n"
-                 "s_cbranch_scc1 1b\n"
-                 "2:\n"
-                 "s_waitcnt lgkmcnt(0)\n"
-                 : [off] "+s"(off1), [off2] "+s"(off2), [resume] "+v"(resume1), [resume2] "+v"(resume2), [ax] "+v"(ax),
-                   [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2), [ay2] "+v"(ay2), [az2] "+v"(az2), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2),
-                   [inv] "=&v"(inv), [f] "=&v"(f), [t] "=&v"(t)
-                 : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end1),
-                   [end2] "s"(end2)
-                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
-                   "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s60", "s61", "s62", "s63", "s64",
-                   "s65", "s68", "s69", "s70", "s71", "s72", "s73", "vcc", "scc", "memory");
-}
-
 template <int K>
-__global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ nodes, const TreeInfo *info_in,
-                                                       const float4 *__restrict__ posm_s,
-                                                       const uint32_t *__restrict__ perm, Bodies cur, Bodies nxt,
-                                                       WalkParams P) {
+__global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ nodes, const WalkTable *tab,
+                                                       const TreeInfo *info_in, const float4 *__restrict__ posm_s,
+                                                       const uint32_t *__restrict__ perm, WalkParams P) {
     __shared__ float part[K][3][64];
     const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t rank = P.rank_begin + (int64_t)lb * 64 + lane;
     const bool valid = rank < P.rank_end;
-    const int64_t num_nodes = (info_in->error != 0) ? 0 : info_in->num_nodes;
+    const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
+    const int64_t num_nodes = frozen ? 0 : info_in->num_nodes;
 
-    float px = 0.f, py = 0.f, pz = 0.f;
+    WalkCtx C;
+    C.nodes = nodes;
+    C.px = C.py = C.pz = 0.f;
+    C.band2 = __builtin_amdgcn_readfirstlane(info_in->band2);
+    uint32_t j = 0;
     if (valid) {
         const float4 p = posm_s[rank];
-        px = p.x; py = p.y; pz = p.z;
+        C.px = p.x; C.py = p.y; C.pz = p.z;
+        j = perm[rank];
     }
+    C.b64 = Body64{tab, P.curbuf, j};
     unsigned resume = valid ? 0u : 0xffffffffu;
     float ax = 0.f, ay = 0.f, az = 0.f;
     // wave-uniform range (w is the wave index): tell the compiler so
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * w / K) * kNodeBytes);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * (w + 1) / K) * kNodeBytes);
     if (lo < hi) {
-        const unsigned c0 = __builtin_amdgcn_readfirstlane(lo == 0u ? 0u : seek(nodes, lo, px, py, pz, P.eps2, resume));
-        if (c0 < hi) walk_range_asm(nodes, c0, hi, px, py, pz, P.eps2, resume, ax, ay, az);
+        const unsigned c0 = __builtin_amdgcn_readfirstlane(lo == 0u ? 0u : seek(C, P, lo, resume));
+        if (c0 < hi) walk_span<false>(C, P, c0, hi, resume, ax, ay, az);
     }
     part[w][0][lane] = ax; part[w][1][lane] = ay; part[w][2][lane] = az;
     __syncthreads();
@@ -843,18 +1057,44 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     for (int k = 1; k < K; k++) {
         ax += part[k][0][lane]; ay += part[k][1][lane]; az += part[k][2][lane];
     }
+    integrate(tab, j, rank, ax, ay, az, P, frozen);
+}
+
+// ---------------------------------------------------------------------------------------
+// Measurement only (NBMI_WALK_LANE=1): every lane walks on its own (own cursor, vector loads of the node
+// record).  No lane ever idles for another's descent, but every visit is a 64-address gather.  Same
+// accepted sets; kept as the yardstick for what a divergent visit costs on this chip.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ nodes, const WalkTable *tab,
+                                                      const TreeInfo *info_in, const float4 *__restrict__ posm_s,
+                                                      const uint32_t *__restrict__ perm, WalkParams P) {
+    const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
+    if (rank >= P.rank_end) return;
+    const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
+    const unsigned nn = frozen ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);
+    const unsigned band2 = info_in->band2;
+    const float4 p = posm_s[rank];
     const uint32_t j = perm[rank];
-    double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
-    const double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j], m0 = cur.m[j];
-    const int32_t id0 = cur.id[j];
-    vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
-    vx *= P.damping; vy *= P.damping; vz *= P.damping;
-    nxt.vx[rank] = vx; nxt.vy[rank] = vy; nxt.vz[rank] = vz;
-    nxt.x[rank] = x0 + vx * P.dt;
-    nxt.y[rank] = y0 + vy * P.dt;
-    nxt.z[rank] = z0 + vz * P.dt;
-    nxt.m[rank] = m0;
-    nxt.id[rank] = id0;
+    const Body64 b64{tab, P.curbuf, j};
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    unsigned off = 0u;
+    while (off < nn) {
+        const char *q = reinterpret_cast<const char *>(nodes) + off;
+        const float2 a0 = *reinterpret_cast<const float2 *>(q), a1 = *reinterpret_cast<const float2 *>(q + 8);
+        const float2 b = *reinterpret_cast<const float2 *>(q + 16);
+        const float4 a = make_float4(a0.x, a0.y, a1.x, a1.y);
+        const float dx = a.x - p.x, dy = a.y - p.y, dz = a.z - p.z;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
+        const int d2b = __float_as_int(d2), hi = __float_as_int(b.x), lo = hi - (int)band2;
+        bool take = hi < d2b;
+        if (!take && lo < d2b) take = (hi == 0) || exact_take(off, b64);
+        const float inv = __builtin_amdgcn_rsqf(d2);
+        const float f = take ? a.w * inv * inv * inv : 0.f;
+        ax = fmaf(dx, f, ax); ay = fmaf(dy, f, ay); az = fmaf(dz, f, az);
+        off = take ? __float_as_uint(b.y) : off + kNodeBytes;
+    }
+    integrate(tab, j, rank, ax, ay, az, P, frozen);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1135,6 +1375,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_ranks(const RunRec *__restrict
     }
     if (rank >= nt) {
         info->error = 2;
+        info->sticky_error = 2;
         return;
     }
     hi[rank] = me.hi;
@@ -1160,6 +1401,8 @@ struct nbmi_sim {
     Moment *S = nullptr;
     ScanVal *tile_sum = nullptr;
     Node *nodes = nullptr;
+    Node64 *nodes64 = nullptr;  // float64 twin rows of the internal cells (near-tie re-decision)
+    WalkTable *wtab = nullptr;  // device copy of the walk's per-handle constants
     uint8_t *node_level = nullptr;
     int32_t *node_ref = nullptr;  // first body (sorted rank) of every node; queries only
     int32_t *cell_r = nullptr;  // internal-cell list: first body and level
@@ -1184,6 +1427,7 @@ struct nbmi_sim {
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
+    int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
     // timers
@@ -1249,7 +1493,8 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
                                             (size_t)n, 0, 63, st));
-    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, n);
+    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, s->idx, n);
+    std::swap(s->perm, s->idx);  // the tie-fixed permutation is `perm` from here on; the old buffer takes the next step's indices
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
     k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s);
     return 0;
@@ -1261,18 +1506,20 @@ int enqueue_global_tree(nbmi_sim *s) {
     k_delta<<<nblocks(n), kBlock, 0, st>>>(s->t_hi, s->t_lo, n, s->delta, s->cnt);
     {
         const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
-        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(s->t_posm, s->cnt, n, s->tile_sum);
+        // moments from the float64 state through the sort permutation; run exchange: from the fp32 records
+        const MomentSrc src{s->buf[s->curbuf], s->world > 0 ? nullptr : s->perm, s->t_posm, s->G};
+        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum);
         k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
-        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(s->t_posm, s->cnt, n, s->tile_sum, s->S, s->Pex);
+        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum, s->S, s->Pex);
     }
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->node_capacity, s->nodes,
-                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->info);
+                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->softening, s->info);
     // one thread per internal cell; the count lives on the device, so launch for the row budget
     k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
-                                                                  n, s->G, inv_theta2, s->node_capacity, s->nodes,
-                                                                  s->node_level, s->node_ref, s->info);
+                                                                  n, s->softening, inv_theta2, s->node_capacity, s->nodes,
+                                                                  s->nodes64, s->node_level, s->node_ref, s->info);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1295,7 +1542,6 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
 int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t n = s->n;
     hipStream_t st = s->stream;
-    Bodies cur = s->buf[s->curbuf], nxt = s->buf[1 - s->curbuf];
     WalkParams P;
     P.rank_begin = integrate ? s->shard_begin : 0;
     P.rank_end = integrate ? s->shard_end : n;
@@ -1307,6 +1553,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
     P.pair = s->walk_pair;
+    P.curbuf = s->curbuf;
 
     // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on
     // the size of the tree (not on the shard), so that every sharding adds up the same partial sums.
@@ -1317,7 +1564,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     while (parts < 16 && tree_groups <= 4300 && tree_groups * parts * 2 <= s->split_max_waves) parts *= 2;
     if (integrate && !guard && s->world == 0 && parts > 1) {
 #define NBMI_SPLIT(KV) \
-    k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, P)
+    k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P)
         if (parts == 2) NBMI_SPLIT(2);
         else if (parts == 4) NBMI_SPLIT(4);
         else if (parts == 8) NBMI_SPLIT(8);
@@ -1328,8 +1575,13 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     }
     const int wb = s->walk_block;
     const int gb = (int)((cntr + wb - 1) / wb);
+    if (integrate && s->walk_lane) {  // measurement only, see k_walk_lane
+        k_walk_lane<<<gb, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P);
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define NBMI_WALK(I, C, G) \
-    k_walk<I, C, G><<<gb, wb, 0, st>>>(s->nodes, s->info, s->posm_s, s->perm, cur, nxt, acc_out, P, s->info)
+    k_walk<I, C, G><<<gb, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, acc_out, P, s->info)
     if (integrate) {
         if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
     } else {
@@ -1377,13 +1629,22 @@ int check_device_error(nbmi_sim *s) {
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
-    if (h.error == 2) {
+    if (h.error || h.sticky_error) {
+        // reported once: clear the sticky word so the handle can go on after nbmi_set_state / a retry.  The
+        // bodies stand at the last step that completed (the walk froze them while the word was set).
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->sticky_error, 0, sizeof(int), s->stream));
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->error, 0, sizeof(int), s->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->tree_valid = false;
+    }
+    if (h.error == 2 || h.sticky_error == 2) {
         nbmi::set_error("run exchange: the gathered runs do not hold the %lld bodies announced", (long long)s->nt);
         return NBMI_ERR_ARG;
     }
-    if (h.error) {
-        nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference)",
-                        (long long)h.num_nodes, (long long)s->node_capacity);
+    if (h.error || h.sticky_error) {
+        nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference); the "
+                        "bodies were not advanced from that step on",
+                        (long long)(h.sticky_error ? h.sticky_nodes : h.num_nodes), (long long)s->node_capacity);
         return NBMI_ERR_CAPACITY;
     }
     return 0;
@@ -1415,6 +1676,18 @@ void nbmi_destroy(nbmi_sim *s) {
     delete s;
 }
 
+// measurement / tuning knobs, read once per handle by both constructors
+static void read_env_knobs(nbmi_sim *s) {
+    if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);
+    if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
+    if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
+    if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
+    if (const char *e = getenv("NBMI_WALK_BLOCK")) {
+        const int b = atoi(e);
+        if (b == 64 || b == 128 || b == 256) s->walk_block = b;
+    }
+}
+
 static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const double *mass) {
     const int64_t n = s->n;
     NBMI_HIP_CHECK(hipSetDevice(s->device));
@@ -1433,7 +1706,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
             dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
-            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity + 2) ||
+            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->node_ref, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
             dev_alloc(s, &s->cell_lev, s->node_capacity - n))
             return -2;
@@ -1488,13 +1761,7 @@ nbmi_sim *nbmi_create(int64_t n, const double *pos, const double *vel, const dou
     nbmi_sim *s = new nbmi_sim();
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
-    if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);  // tuning knob (measurement only)
-    if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
-    if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
-    if (const char *e = getenv("NBMI_WALK_BLOCK")) {
-        const int b = atoi(e);
-        if (b == 64 || b == 128 || b == 256) s->walk_block = b;
-    }
+    read_env_knobs(s);
     if (create_impl(s, pos, vel, mass) != 0) {
         std::string keep = nbmi::get_error();
         nbmi_destroy(s);
@@ -1521,7 +1788,7 @@ nbmi_sim *nbmi_create_generated(int distribution, int64_t n, double spawn_radius
     nbmi_sim *s = new nbmi_sim();
     s->n = n; s->method = method; s->device = device;
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
-    if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);
+    read_env_knobs(s);
     int rc = create_impl(s, nullptr, nullptr, nullptr);
     if (rc == 0) {
         Bodies &b = s->buf[0];
@@ -1670,6 +1937,7 @@ int nbmi_set_state(nbmi_sim *s, const double *pos, const double *vel) {
     NBMI_HIP_CHECK(hipMemcpyAsync(dvel, vel, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, s->stream));
     k_set_state_perm<<<nblocks(n), kBlock, 0, s->stream>>>(dpos, dvel, s->buf[s->curbuf], n);
     NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemsetAsync(&s->info->sticky_error, 0, sizeof(int), s->stream));  // a fresh state: drop a pending capacity error
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->tree_valid = false;
     return 0;
@@ -1691,7 +1959,7 @@ int nbmi_get_accelerations_f64(nbmi_sim *s, double *out) {
     double *acc = (double *)s->stage;
     if (s->method == NBMI_METHOD_BARNES_HUT) {
         if (int rc = enqueue_tree(s, -1)) return rc;
-        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 16 * sizeof(unsigned long long), s->stream));
+        NBMI_HIP_CHECK(hipMemsetAsync(&s->info->wave_visits, 0, 17 * sizeof(unsigned long long), s->stream));
         if (int rc = enqueue_walk(s, false, 0.0, acc)) return rc;
     } else {
         if (int rc = launch_direct<false>(s, 0.0, acc)) return rc;
@@ -1810,7 +2078,7 @@ int nbmi_get_timers(nbmi_sim *s, double *ms5, int64_t *count, int reset) {
     return 0;
 }
 
-int nbmi_walk_counters(nbmi_sim *s, int64_t *out8 /* 16 entries */) {
+int nbmi_walk_counters(nbmi_sim *s, int64_t *out8 /* 17 entries */) {
     if (int rc = check_handle(s)) return rc;
     int64_t *out3 = out8;
     if (!out3) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
@@ -1821,6 +2089,7 @@ int nbmi_walk_counters(nbmi_sim *s, int64_t *out8 /* 16 entries */) {
     for (int w = 0; w < 4; w++) out8[3 + w] = (int64_t)h.win_miss[w];
     out8[7] = (int64_t)h.jumps;
     for (int x = 0; x < 8; x++) out8[8 + x] = (int64_t)h.xcd_visits[x];
+    out8[16] = (int64_t)h.band_visits;
     return 0;
 }
 
@@ -1874,7 +2143,8 @@ int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_ro
     if (dev_alloc(s, &s->t_hi, nt) || dev_alloc(s, &s->t_lo, nt) || dev_alloc(s, &s->t_posm, nt) ||
         dev_alloc(s, &s->delta, nt) || dev_alloc(s, &s->cnt, nt + 1) || dev_alloc(s, &s->Pex, nt + 1) ||
         dev_alloc(s, &s->S, nt + 1) || dev_alloc(s, &s->tile_sum, (nt + 1) / kScanTile + 2) ||
-        dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->node_level, s->node_capacity) ||
+        dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
+        dev_alloc(s, &s->node_level, s->node_capacity) ||
         dev_alloc(s, &s->node_ref, s->node_capacity) ||
         dev_alloc(s, &s->cell_r, s->node_capacity - nt) || dev_alloc(s, &s->cell_lev, s->node_capacity - nt))
         return NBMI_ERR_HIP;

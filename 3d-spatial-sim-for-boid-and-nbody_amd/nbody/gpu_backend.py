@@ -247,12 +247,16 @@ class HIPBarnesHutSimulation(_HIPSimulation):
     def build_tree(self):
         _nat.check(self._lib.nbmi_build_tree(self._h), "nbmi_build_tree")
 
-    def tree_stats(self):
-        """num_nodes as build_octree returns it, max depth, root half size (compute_bounds)."""
+    def tree_stats(self, depth=True):
+        """num_nodes as build_octree returns it, max depth, root half size (compute_bounds).
+        depth=False skips the reduction kernel behind max_depth (one small D2H copy only)."""
         nn, md, b = C.c_int64(0), C.c_int32(0), C.c_double(0)
-        _nat.check(self._lib.nbmi_tree_stats(self._h, C.addressof(nn), C.addressof(md), C.addressof(b)),
-                   "nbmi_tree_stats")
-        return dict(num_nodes=int(nn.value), max_depth=int(md.value), bounds=float(b.value))
+        _nat.check(self._lib.nbmi_tree_stats(self._h, C.addressof(nn), C.addressof(md) if depth else None,
+                                             C.addressof(b)), "nbmi_tree_stats")
+        out = dict(num_nodes=int(nn.value), bounds=float(b.value))
+        if depth:
+            out["max_depth"] = int(md.value)
+        return out
 
     def morton_keys(self):
         """(key_hi, key_lo) uint64 per body, caller's order, for the last built tree."""
@@ -270,11 +274,11 @@ class HIPBarnesHutSimulation(_HIPSimulation):
         return level, key
 
     def walk_counters(self):
-        out = np.zeros(16, dtype=np.int64)
+        out = np.zeros(17, dtype=np.int64)
         _nat.check(self._lib.nbmi_walk_counters(self._h, _nat.ptr(out)), "nbmi_walk_counters")
         return dict(wave_visits=int(out[0]), lane_visits=int(out[1]), lane_accepts=int(out[2]),
                     window_misses={8 << w: int(out[3 + w]) for w in range(4)}, jumps=int(out[7]),
-                    xcd_visits=[int(v) for v in out[8:16]])
+                    xcd_visits=[int(v) for v in out[8:16]], band_visits=int(out[16]))
 
     def key_order(self):
         """Body indices along the octant-key order of the last built tree."""
@@ -311,7 +315,7 @@ class HIPDirectSimulation(_HIPSimulation):
 
 # Reference thresholds (:618-620) exist because its GPU paths are O(N^2); the HIP Barnes-Hut
 # backend is O(N log N) like the reference's Metal one, so it takes every size.
-HIP_BH_THRESHOLD = 400_000_000
+HIP_BH_THRESHOLD = 100_000_000  # = kMaxBodies of libnbmi.so (node links are 32-bit byte offsets): beyond it the factory returns None
 
 
 def create_gpu_simulation(positions: np.ndarray, velocities: np.ndarray, masses: np.ndarray, G: float,

@@ -134,7 +134,8 @@ class NBodySimulation:
         self.damping = float(cfg["damping"])
         self.point_size = float(cfg["point_size"])
         self.max_speed_color = float(cfg["max_speed_color"])
-        self.current_bounds = self.spawn_radius * 2
+        self._tree_facts = {"num_nodes": 0, "bounds": self.spawn_radius * 2}
+        self._tree_facts_stale = False
         if seed is not None:  # the reference never seeds; extra kwarg for reproducible runs
             np.random.seed(seed)
         gen = _LIVE_ICS.get(cfg.get("distribution", "galaxy"), _ic_uniform)
@@ -145,7 +146,6 @@ class NBodySimulation:
         self._use_gpu = False
         self._backend = None
         self._init_gpu_backend()
-        self._num_tree_nodes = 0
         self._visible_mask = np.ones(num_bodies, dtype=np.bool_)
         self._visible_count = num_bodies
         self.fog_end = float(config.CAMERA["far_clip"])
@@ -174,10 +174,23 @@ class NBodySimulation:
         self._gpu_sim.compute_colors(self.max_speed_color)
         self.positions = self._gpu_sim.get_positions().astype(np.float64)
         self.colors = self._gpu_sim.get_colors()
-        if hasattr(self._gpu_sim, "tree_stats"):
-            st = self._gpu_sim.tree_stats()
-            self._num_tree_nodes = st["num_nodes"]
-            self.current_bounds = st["bounds"]
+        self._tree_facts_stale = True  # fetched when somebody reads them (HUD), not once per frame
+
+    def _tree_fact(self, key):
+        if self._tree_facts_stale and hasattr(self._gpu_sim, "tree_stats"):
+            self._tree_facts = self._gpu_sim.tree_stats(depth=False)
+            self._tree_facts_stale = False
+        return self._tree_facts[key]
+
+    @property
+    def _num_tree_nodes(self):
+        """HUD number of the reference (nbody_main.py:153): nodes of the last step's octree."""
+        return self._tree_fact("num_nodes")
+
+    @property
+    def current_bounds(self):
+        """Root half size of the last step's octree (reference attribute, simulation.py:822)."""
+        return self._tree_fact("bounds")
 
     def sync_velocities(self):
         """Fetch velocities from the device (the reference's GPU path never refreshes them)."""

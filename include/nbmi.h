@@ -83,7 +83,9 @@ int nbmi_get_positions_f32(nbmi_sim *sim, float *out_xyz);
 int nbmi_get_velocities_f64(nbmi_sim *sim, double *out_xyz);
 /* get_colors() -> (N,3) float32 (gpu_backend.py:402-404). */
 int nbmi_get_colors_f32(nbmi_sim *sim, float *out_rgb);
-/* sync(): gpu_backend.py:406-409.  Also reports deferred device-side errors (capacity). */
+/* sync(): gpu_backend.py:406-409.  Also reports deferred device-side errors.  NBMI_ERR_CAPACITY is
+ * sticky on the device: from the substep whose octree did not fit, the bodies are no longer advanced
+ * (they stay at the last completed step) until a sync / getter has reported the error once. */
 int nbmi_sync(nbmi_sim *sim);
 
 /* ---- supersets of the protocol (parity / measurement hooks) --------------------------- */
@@ -119,8 +121,10 @@ int nbmi_enable_timers(nbmi_sim *sim, int enable);
 int nbmi_get_timers(nbmi_sim *sim, double *ms5, int64_t *count, int reset);
 /* Work counters of the last counted walk (nbmi_get_accelerations_f64): [wave-level node visits,
  * lane-level visits, lane accepts, node-window misses for windows of 8/16/32/64 nodes,
- * non-sequential cursor moves, wave-level visits executed on each of the 8 XCDs] (16 values). */
-int nbmi_walk_counters(nbmi_sim *sim, int64_t *out16);
+ * non-sequential cursor moves, wave-level visits executed on each of the 8 XCDs, lane visits whose
+ * opening test was a near-tie in fp32 and was re-decided in float64 like the reference
+ * (simulation.py:252-258)] (17 values). */
+int nbmi_walk_counters(nbmi_sim *sim, int64_t *out17);
 
 /* Multi-GPU (one process per GPU).  A handle created with nbmi_create holds ALL bodies; with a
  * shard set, step() integrates only the key-sorted ranks [begin,end) (direct method: the body

@@ -309,6 +309,28 @@ void nbref_direct_forces(const double *pos, const double *masses, double *acc, d
     }
 }
 
+/* Same sum for a SUBSET of the bodies (rows idx[0..k-1]) against all n: lets a test check the all-pairs
+ * kernel at BASELINE config 3's full size on a sample (the full N^2 in float64 would take hours). */
+void nbref_direct_forces_subset(const double *pos, const double *masses, const int64_t *idx, int64_t k, double *acc,
+                                double G, double softening, int64_t n) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t s = 0; s < k; s++) {
+        int64_t i = idx[s];
+        double px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+        double ax = 0.0, ay = 0.0, az = 0.0;
+        for (int64_t j = 0; j < n; j++) {
+            if (i == j) continue;
+            double dx = pos[3 * j] - px, dy = pos[3 * j + 1] - py, dz = pos[3 * j + 2] - pz;
+            double dist_sq = dx * dx + dy * dy + dz * dz + softening * softening;
+            double inv = 1.0 / sqrt(dist_sq);
+            double inv3 = inv * inv * inv;
+            double f = G * masses[j] * inv3;
+            ax += f * dx; ay += f * dy; az += f * dz;
+        }
+        acc[3 * s] = ax; acc[3 * s + 1] = ay; acc[3 * s + 2] = az;
+    }
+}
+
 /* nbody/gpu_backend.py:243-257 update_bodies_cuda: v=(v+a dt)*damping; x+=v dt */
 void nbref_direct_update(double *pos, double *vel, const double *acc, double dt, double damping, int64_t n) {
 #pragma omp parallel for schedule(static)
@@ -466,6 +488,79 @@ void nbref_group_walk_stats(const double *pos, const int64_t *order, int64_t n, 
     }
     (void)body_idx;
     out[0] = sum_union; out[1] = sum_body; out[2] = ngroups; out[3] = max_union;
+}
+
+/* Design analysis (round 2): like nbref_group_walk_stats, plus what the lock-step walk of a group of
+ * `gs` bodies looks like visit by visit.  For every node the group visits:
+ *   a = members taking part (all their ancestors were opened by them), t = of those, members that
+ *   accept the node (leaf or opening test passed), o = a - t members that open it.
+ * hist_active[a] += 1 (a = 1..gs);  cls[0..2] = visits with o == 0 (unanimous accept) / t == 0
+ * (unanimous open) / mixed;  cls[3..5] = sum of a over those classes;  cls[6] = sum of t (accepts);
+ * cls[7] = visits at which a == gs. */
+void nbref_group_walk_hist(const double *pos, const int64_t *order, int64_t n, int gs,
+                           const double *half, const double *com, const int32_t *children,
+                           const uint8_t *is_leaf, double theta, double softening, int64_t *hist_active,
+                           int64_t *cls) {
+    const double eps2 = softening * softening;
+    int64_t ngroups = (n + gs - 1) / gs;
+    for (int i = 0; i <= gs; i++) hist_active[i] = 0;
+    for (int i = 0; i < 8; i++) cls[i] = 0;
+#pragma omp parallel
+    {
+        int64_t *h = (int64_t *)calloc((size_t)gs + 1, sizeof(int64_t));
+        int64_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t g = 0; g < ngroups; g++) {
+            int64_t lo = g * gs, hi = lo + gs > n ? n : lo + gs;
+            int cnt = (int)(hi - lo);
+            typedef unsigned __int128 mask_t;
+            int cap = 4096, sp = 0;
+            int32_t *sn = (int32_t *)malloc(sizeof(int32_t) * cap);
+            mask_t *sm = (mask_t *)malloc(sizeof(mask_t) * cap);
+            sn[0] = 0; sm[0] = (cnt == 128) ? ~(mask_t)0 : ((((mask_t)1) << cnt) - 1); sp = 1;
+            while (sp > 0) {
+                sp--;
+                int32_t node = sn[sp];
+                mask_t mask = sm[sp];
+                mask_t open = 0;
+                int a = 0, o = 0;
+                for (int l = 0; l < cnt; l++) {
+                    if (!((mask >> l) & 1)) continue;
+                    a++;
+                    int64_t i = order[lo + l];
+                    if (is_leaf[node]) continue;
+                    double dx = com[3 * node] - pos[3 * i], dy = com[3 * node + 1] - pos[3 * i + 1],
+                           dz = com[3 * node + 2] - pos[3 * i + 2];
+                    double dist = sqrt(dx * dx + dy * dy + dz * dz + eps2);
+                    if (!(half[node] * 2.0 / dist < theta)) { open |= ((mask_t)1) << l; o++; }
+                }
+                h[a]++;
+                int k = (o == 0) ? 0 : (o == a ? 1 : 2);
+                c[k]++; c[3 + k] += a; c[6] += a - o;
+                if (a == gs) c[7]++;
+                if (open) {
+                    for (int ch8 = 0; ch8 < 8; ch8++) {
+                        int32_t ch = children[8 * (int64_t)node + ch8];
+                        if (ch >= 0) {
+                            if (sp == cap) {
+                                cap *= 2;
+                                sn = (int32_t *)realloc(sn, sizeof(int32_t) * cap);
+                                sm = (mask_t *)realloc(sm, sizeof(mask_t) * cap);
+                            }
+                            sn[sp] = ch; sm[sp] = open; sp++;
+                        }
+                    }
+                }
+            }
+            free(sn); free(sm);
+        }
+#pragma omp critical
+        {
+            for (int i = 0; i <= gs; i++) hist_active[i] += h[i];
+            for (int i = 0; i < 8; i++) cls[i] += c[i];
+        }
+        free(h);
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -58,6 +58,11 @@ def _bind(lib):
     lib.nbref_colors.argtypes = [_f64p, _f32p, _i64, _dbl]
     lib.nbref_direct_forces.restype = None
     lib.nbref_direct_forces.argtypes = [_f64p, _f64p, _f64p, _dbl, _dbl, _i64]
+    lib.nbref_direct_forces_subset.restype = None
+    lib.nbref_direct_forces_subset.argtypes = [_f64p, _f64p, _i64p, _i64, _f64p, _dbl, _dbl, _i64]
+    lib.nbref_group_walk_hist.restype = None
+    lib.nbref_group_walk_hist.argtypes = [_f64p, _i64p, _i64, C.c_int, _f64p, _f64p, _i32p, _u8p, _dbl, _dbl, _i64p,
+                                          _i64p]
     lib.nbref_direct_update.restype = None
     lib.nbref_direct_update.argtypes = [_f64p, _f64p, _f64p, _dbl, _dbl, _i64]
     lib.nbref_step.restype = _i64
@@ -202,6 +207,14 @@ def build_vertices(pos, vel, col, visible_indices, cone_length, cone_radius, L=N
 def direct_forces(pos, masses, G, softening, L=None):
     acc = np.zeros((len(pos), 3))
     (L or lib()).nbref_direct_forces(pos, masses, acc, G, softening, len(pos))
+    return acc
+
+
+def direct_forces_subset(pos, masses, idx, G, softening, L=None):
+    """compute_forces_brute_cuda's sum (nbody/gpu_backend.py:145-174) for the rows `idx` only."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    acc = np.zeros((len(idx), 3))
+    (L or lib()).nbref_direct_forces_subset(pos, masses, idx, len(idx), acc, G, softening, len(pos))
     return acc
 
 

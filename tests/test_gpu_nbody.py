@@ -206,6 +206,70 @@ def test_capacity_error_is_reported_not_hung(gpu):
     sim.close()
 
 
+def test_capacity_error_in_the_middle_of_step_many_is_sticky(gpu):
+    """VERDICT r1 / ADVICE: an octree that does not fit in substep 2 of 3 used to make that substep coast
+    force-free and the flag was gone by the time the host looked.  Now the error is sticky on the device and
+    the bodies stay at the last completed step.  G = 0 (pure drift): pairs start 1.0 apart and meet to
+    within 1e-9 after exactly one step, where their 37-level chains overflow the 4N + 4096 rows."""
+    n_pairs, dt, sep = 1500, 0.1, 1.0
+    rng = np.random.RandomState(7)
+    base = rng.uniform(-50, 50, (n_pairs, 3))
+    pos = np.concatenate([base, base + [sep, 0.0, 0.0]])
+    v = (sep - 1e-9) / (2 * dt)
+    vel = np.concatenate([np.tile([v, 0.0, 0.0], (n_pairs, 1)), np.tile([-v, 0.0, 0.0], (n_pairs, 1))])
+    sim = _bh(gpu, pos, vel, np.ones(2 * n_pairs), 0.0, 0.1)
+    sim.step_many(dt, 3)
+    with pytest.raises(RuntimeError, match="octree needs"):
+        sim.sync()
+    x = sim.get_positions_f64()  # reported once; the state is the one after substep 1
+    assert np.array_equal(x, pos + vel * dt)
+    assert np.array_equal(sim.get_velocities(), vel)
+    # the handle goes on after a new state
+    sim.set_state(pos, vel)
+    sim.step(dt)
+    sim.sync()
+    assert np.array_equal(sim.get_positions_f64(), pos + vel * dt)
+    sim.close()
+
+
+def test_long_run_of_equal_upper_key_words(gpu, oracle):
+    """10^5 bodies inside ONE level-21 cell (an escaper at 10^6 inflates the root cube so
+    that such a cell is ~1 wide).  All of them tie on the 63-bit upper key word; the tie-fix orders them by
+    the lower word in parallel (it used to be a one-thread insertion sort, O(L^2))."""
+    import time
+    n = 100_000
+    rng = np.random.RandomState(3)
+    b = 1.0e6 * 1.1 + 10.0
+    cell = 2 * b / 2 ** 21
+    k = np.floor((np.array([123.4, -56.7, 8.9]) + b) / cell)
+    centre = -b + (k + 0.5) * cell
+    pos = np.concatenate([[[1.0e6, 0.0, 0.0]], centre + rng.uniform(-0.3, 0.3, (n - 1, 3)) * cell])
+    mass = np.ones(n)
+    assert oracle.compute_bounds(pos) == b
+    ohi, olo = oracle.body_keys(pos, b)
+    assert len(np.unique(ohi[1:])) == 1  # one run of n - 1 equal upper words
+    sim = _bh(gpu, pos, np.zeros_like(pos), mass, 1.0, 0.01)
+    sim.build_tree()
+    sim.sync()
+    t0 = time.perf_counter()
+    sim.build_tree()
+    sim.sync()
+    t_build = time.perf_counter() - t0
+    order = sim.key_order()
+    expect = np.lexsort((np.arange(n), olo, ohi)).astype(np.int32)
+    assert np.array_equal(order, expect)
+    hi, lo = sim.morton_keys()
+    assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    nd = oracle.NodeArrays(4 * n + 4096)
+    nn = oracle.build_octree(pos, mass, b, nd, cap=oracle.UNCAPPED)
+    st = sim.tree_stats()
+    print(f"run of {n - 1} tied upper words: build {1e3 * t_build:.2f} ms, nodes {st['num_nodes']} depth {st['max_depth']}")
+    assert st["num_nodes"] == nn
+    assert t_build < 0.25
+    assert np.isfinite(sim.accelerations()).all()
+    sim.close()
+
+
 def test_coincident_bodies_terminate(gpu):
     """Exactly coincident bodies make the reference subdivide until its node cap; here the key
     runs out at 42 levels and both become leaves of the level-42 cell.  Must terminate."""
@@ -370,6 +434,31 @@ def test_nbody_simulation_object(gpu):
         sim.draw()
 
 
+def test_nbody_simulation_update_against_the_oracle(gpu, oracle):
+    """SURVEY 8(a) row 8 through the object API: seeded NBodySimulation, update() ten times (dt capped to
+    0.02, simulation.py:799-807) against the oracle stepping the same bodies, then colours
+    (compute_colors_by_velocity with config max_speed_color, simulation.py:873-878) and the HUD numbers."""
+    from nbody import NBodySimulation
+    sim = NBodySimulation(20_000, seed=5)
+    p0, v0, m0 = sim.positions.copy(), sim.velocities.copy(), sim.masses.copy()
+    o = oracle.BHStepper(p0, v0, m0, sim.theta, sim.G, sim.softening, sim.damping)
+    for _ in range(10):
+        sim.update(0.05)
+        b_last = oracle.compute_bounds(o.pos)  # root cube of the tree this step builds
+        o.step(0.02)
+    # update() hands back get_positions() (float32) widened to float64, like the reference (:814)
+    scale = np.abs(o.pos).max()
+    assert sim.positions.dtype == np.float64
+    assert np.abs(sim.positions - o.pos).max() <= np.spacing(np.float32(scale)) + 1e-6 * scale
+    vel = sim.sync_velocities()
+    assert np.abs(vel - o.vel).max() <= 1e-5 * np.abs(o.vel).max()
+    col = oracle.compute_colors_by_velocity(o.vel, sim.max_speed_color)
+    assert np.abs(sim.colors - col).max() <= 1e-4
+    assert sim._num_tree_nodes == o.num_nodes
+    assert abs(sim.current_bounds - b_last) <= 1e-6 * b_last
+    sim._gpu_sim.close()
+
+
 def test_galaxy_1m_tree_and_forces_vs_oracle(gpu, oracle):
     """BASELINE config 2 inputs (galaxy 1 M, R=800, G=0.07, eps=1.5, theta=0.5): node count and
     depth equal the oracle's serial-insertion tree; accelerations within the fp32 tolerance."""
@@ -395,8 +484,9 @@ def test_galaxy_1m_tree_and_forces_vs_oracle(gpu, oracle):
     print(f"1M acc rel err max {err.max():.3e} p99.9 {np.percentile(err, 99.9):.3e} median {np.median(err):.3e}")
     print("   counters", wc, "oracle", ost)
     assert ost["dropped"] == 0
-    assert np.median(err) <= 5e-6 and np.percentile(err, 99.9) <= 2e-4 and err.max() <= 5e-3
-    assert abs(wc["lane_accepts"] - ost["accepted"]) <= 1e-4 * ost["accepted"]
+    assert np.median(err) <= 5e-6 and np.percentile(err, 99.9) <= 2e-5 and err.max() <= 1e-4
+    assert wc["lane_accepts"] == ost["accepted"]  # accepted (body, node) sets equal the oracle's, ties included
+    print(f"   near-tie lane visits re-decided in float64: {wc['band_visits']} of {wc['lane_visits']}")
     # 3 steps vs the oracle stepper
     ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0)
     for _ in range(3):
@@ -404,6 +494,80 @@ def test_galaxy_1m_tree_and_forces_vs_oracle(gpu, oracle):
     sim.step_many(0.05, 3)
     rel = _traj_check(sim.get_positions_f64(), ostep.pos, 800.0, "galaxy1m step 3")
     assert rel.max() <= 1e-5
+    sim.close()
+
+
+def test_accept_sets_equal_the_oracles_exactly_200k(gpu, oracle):
+    """Near-ties of the fp32 opening test are re-decided in float64 like the reference
+    (simulation.py:252-258): the per-body accepted sets now EQUAL the oracle's, not just to 2e-7."""
+    from tools.presets import generate_distribution
+    n = 200_000
+    np.random.seed(11)
+    p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
+    b = oracle.compute_bounds(p)
+    nd = oracle.NodeArrays.for_bodies(n)
+    nn = oracle.build_octree(p, m, b, nd)
+    for theta in (0.5, 0.8):
+        ref, ost = oracle.compute_forces_barnes_hut(p, m, nd, nn, theta, 0.07, 1.5, stats=True)
+        sim = _bh(gpu, p, v, m, 0.07, 1.5, theta=theta)
+        acc = sim.accelerations()
+        wc = sim.walk_counters()
+        err = _rel_err(acc, ref)
+        print(f"200k theta={theta}: accepts {wc['lane_accepts']} vs {ost['accepted']}, re-decided lane visits "
+              f"{wc['band_visits']} of {wc['lane_visits']}; acc rel err max {err.max():.2e} p99.9 "
+              f"{np.percentile(err, 99.9):.2e}")
+        assert wc["lane_accepts"] == ost["accepted"]
+        assert 0 < wc["band_visits"] < 2e-3 * wc["lane_visits"]
+        assert err.max() <= 1e-4  # no flipped cell any more: only fp32 pair arithmetic is left
+        sim.close()
+
+
+def test_galaxy_200k_100_steps_meets_the_north_star_bound(gpu, oracle):
+    """north_star: <= 1e-4 relative position error vs the CPU reference after 100 steps (theta 0.5, dt 0.05,
+    config-2 constants).  Error relative to the largest coordinate, as scripts/gpu_parity_1m.py reports it;
+    the 1 M-body run of the same check lives in that script (its oracle side takes minutes)."""
+    from tools.presets import generate_distribution
+    n = 200_000
+    np.random.seed(42)
+    p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
+    ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED)
+    sim = _bh(gpu, p, v, m, 0.07, 1.5, theta=0.5)
+    for k in range(100):
+        ostep.step(0.05)
+        sim.step(0.05)
+        if k in (0, 9, 49):
+            e = np.abs(sim.get_positions_f64() - ostep.pos).max() / np.abs(ostep.pos).max()
+            print(f"  after {k + 1} steps: max rel err {e:.3e}")
+    x = sim.get_positions_f64()
+    scale = np.abs(ostep.pos).max()
+    d = np.abs(x - ostep.pos).max(axis=1) / scale
+    print(f"200k x 100 steps: max {d.max():.3e} p99.9 {np.quantile(d, 0.999):.3e} rms {np.sqrt((d ** 2).mean()):.3e}; "
+          f"nodes {sim.tree_stats()['num_nodes']} vs {ostep.num_nodes}")
+    assert d.max() <= 1e-4
+    assert np.quantile(d, 0.999) <= 2e-5 and np.sqrt((d ** 2).mean()) <= 5e-6
+    sim.close()
+
+
+def test_cluster_1m_direct_at_config_3_size(gpu, oracle):
+    """BASELINE config 3 AT SIZE: 1 M-body Plummer cluster (device-side generator, accurate_cluster constants
+    G 0.05, eps 1.0, R 300, dt 0.02), direct O(N^2).  Forces of a 4 096-body sample against the float64
+    all-pairs sum of the reference's CUDA kernel (gpu_backend.py:145-174), then one fused step."""
+    from nbody.gpu_backend import HIPDirectSimulation
+    n, G, eps, dt = 1_000_000, 0.05, 1.0, 0.02
+    sim = HIPDirectSimulation.generated("cluster", n, 300.0, G, eps, 1.0, seed=42)
+    p, v, m = sim.get_positions_f64(), sim.get_velocities(), sim.get_masses()
+    sample = np.linspace(0, n - 1, 4096).astype(np.int64)
+    ref = oracle.direct_forces_subset(p, m, sample, G, eps)
+    acc = sim.accelerations()[sample]
+    err = _rel_err(acc, ref)
+    print(f"cluster 1M direct: sample acc rel err max {err.max():.3e} median {np.median(err):.3e}")
+    assert err.max() <= 5e-5
+    sim.step(dt)
+    x, v1 = sim.get_positions_f64()[sample], sim.get_velocities()[sample]
+    v_ref = v[sample] + ref * dt
+    x_ref = p[sample] + v_ref * dt
+    assert np.abs(v1 - v_ref).max() <= 5e-5 * np.abs(ref).max() * dt + 1e-15
+    assert np.abs(x - x_ref).max() <= 5e-5 * np.abs(ref).max() * dt * dt + 1e-12
     sim.close()
 
 

@@ -91,15 +91,22 @@ def test_rccl_one_rank_group_stream_ordered_exchange(gpu):
                                 device_id=torch.device("cuda", 0))
     except Exception as ex:  # noqa: BLE001 - an environment without a usable RCCL is not a product failure
         pytest.skip(f"RCCL process group unavailable here: {ex}")
+    import os
     try:
-        sh = ShardedBarnesHut(HipShardEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0), len(pos), 0, 1, dist)
-        assert sh.shared is not None  # stream-ordered path selected for the nccl backend
-        sh.step(0.05, 7)
-        sh.engine.sim.sync()
         single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
         single.step_many(0.05, 7)
-        assert np.array_equal(sh.engine.sim.get_positions_f64(), single.get_positions_f64())
-        assert np.array_equal(sh.engine.sim.get_velocities(), single.get_velocities())
+        for opt_in in (False, True):  # default: host-synchronised exchange; NBMI_EXCHANGE_SYNC=0: stream-ordered
+            if opt_in:
+                os.environ["NBMI_EXCHANGE_SYNC"] = "0"
+            try:
+                sh = ShardedBarnesHut(HipShardEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0), len(pos), 0, 1, dist)
+            finally:
+                os.environ.pop("NBMI_EXCHANGE_SYNC", None)
+            assert (sh.shared is not None) == opt_in
+            sh.step(0.05, 7)
+            sh.engine.sim.sync()
+            assert np.array_equal(sh.engine.sim.get_positions_f64(), single.get_positions_f64())
+            assert np.array_equal(sh.engine.sim.get_velocities(), single.get_velocities())
     finally:
         dist.destroy_process_group()
 
