@@ -1456,6 +1456,19 @@ int alloc_bodies(nbmi_sim *s, Bodies *b, int64_t n) {
     return 0;
 }
 
+// (re)writes the device copy of the walk's per-handle constants
+int upload_walk_table(nbmi_sim *s) {
+    WalkTable t;
+    t.buf[0] = s->buf[0];
+    t.buf[1] = s->buf[1];
+    t.n64 = s->nodes64;
+    t.theta = s->theta;
+    t.eps2 = s->softening * s->softening;
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->wtab, &t, sizeof(t), hipMemcpyHostToDevice, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));  // `t` is a stack object
+    return 0;
+}
+
 int check_handle(nbmi_sim *s) {
     if (!s) {
         nbmi::set_error("null nbmi_sim handle");
@@ -1542,6 +1555,10 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
 int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t n = s->n;
     hipStream_t st = s->stream;
+    if (!s->wtab || !s->nodes64) {  // the kernels dereference both: never launch without them
+        nbmi::set_error("internal: walk table not initialised");
+        return NBMI_ERR_ARG;
+    }
     WalkParams P;
     P.rank_begin = integrate ? s->shard_begin : 0;
     P.rank_end = integrate ? s->shard_end : n;
@@ -1714,6 +1731,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         char *t = nullptr;
         if (dev_alloc(s, &t, s->tmp_sort_bytes + 256)) return -2;
         s->tmp_sort = t;
+        if (dev_alloc(s, &s->wtab, 1) || upload_walk_table(s)) return -2;
     }
     // upload AoS host arrays through the staging buffer and split to SoA
     double *dpos = (double *)s->stage, *dvel = dpos + 3 * n, *dm = dvel + 3 * n;
@@ -2151,7 +2169,7 @@ int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_ro
     s->nt = nt;
     s->world = world;
     s->tree_valid = false;
-    return 0;
+    return upload_walk_table(s);  // the node arrays were re-allocated for the whole system
 }
 
 int nbmi_exchange_maxabs(nbmi_sim *s, void *dev_maxabs) {
