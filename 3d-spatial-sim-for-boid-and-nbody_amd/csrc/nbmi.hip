@@ -439,13 +439,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(MomentSrc src, const int3
     }
 }
 
-// Half width K (ulps of d^2, a power of two) of the opening test's uncertainty band; derivation at K9.
-__device__ __forceinline__ unsigned band_half_ulps(double bounds, double eps) {
-    double k = 16.0 + 8.0 * bounds / eps;  // eps == 0: inf
-    if (!(k < 2097152.0)) k = 2097152.0;   // cap 2^21 (band 2^22 ulps = a factor 1.5 ... 2 in d^2)
-    unsigned K = 16u;
-    while ((double)K < k) K <<= 1;
-    return K;
+// Half width K (ulps of d^2) of the opening test's uncertainty band; derivation at K9.
+__device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
+    double k = 8.0 + 7.0 * maxabs / eps;  // eps == 0: inf
+    if (!(k < 2097152.0)) k = 2097152.0;  // cap 2^21 (band 2^22 ulps = a factor 1.5 ... 2 in d^2)
+    return (unsigned)k + 1u;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
         const int64_t total = n + (int64_t)Pex[n];
         if (r == 0) {
             info->num_nodes = total;
-            info->band2 = 2u * band_half_ulps(info->bounds, eps);
+            info->band2 = 2u * band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
         }
         if (total + 1 > capacity) {  // + 1: the sentinel
             if (r == 0) {
@@ -574,7 +572,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
     nd.gm = (float)M;  // the moments are sums of G*m
     // upper edge of the uncertainty band: bits((2 hs)^2 / theta^2) + K  (theta == 0: +inf, never accepted)
     const float s2t = (float)(size * size * inv_theta2);
-    nd.s2t = __int_as_float(__float_as_int(s2t) + (int)band_half_ulps(bounds, eps));
+    nd.s2t = __int_as_float(__float_as_int(s2t) + (int)band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps));
     nd.next_off = (unsigned)(e + (int64_t)Pex[e]) * kNodeBytes;
     nodes[idx] = nd;
     nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
@@ -604,10 +602,10 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 // d^2 falls between the two is re-decided exactly as the reference does it (simulation.py:252-258):
 // float64 body position, float64 centre of mass (double-double prefix sums, see k_scan_*), sqrt and
 // divide.  K (ulps of d^2) bounds the fp32 error: both positions are rounded by <= 2^-24 maxabs, so
-// d^2 is off by <= 2 sqrt(3) d 2^-23 maxabs + a few ulps; the test only matters where d >= eps
-// (smaller cells pass it through eps^2 alone), hence K = 16 + 8 bounds / eps, rounded up to a power of
-// two (TreeInfo.band2 = 2 K).  One extra compare per visit; the float64 path runs for ~1e-4 of the
-// lane visits.
+// d^2 is off by <= 2 sqrt(3) d 2^-23 maxabs + a few ulps, i.e. by <= 6.93 maxabs / d + 4 ulps (one ulp
+// is >= 2^-24 of d^2); the test only matters where d >= eps (smaller cells pass it through eps^2
+// alone), hence K = 8 + 7 maxabs / eps (TreeInfo.band2 = 2 K; 6.5 k ulps = 4e-4 ... 8e-4 of d^2 for the
+// 1 M-body galaxy).  One extra compare per visit; the float64 path runs for ~1.5e-4 of the lane visits.
 // ---------------------------------------------------------------------------------------
 struct WalkParams {
     int64_t rank_begin, rank_end;  // shard of sorted ranks handled by this launch
