@@ -416,26 +416,23 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(MomentSrc src, const int3
                                                        Moment *__restrict__ S, int32_t *__restrict__ Pex) {
     __shared__ ScanVal lds[kBlock / 64];
     __shared__ ScanVal excl[kBlock];
-    // blocked layout: each thread owns kScanItems consecutive elements
+    // blocked layout: each thread owns kScanItems consecutive elements.  The items are loaded twice (thread
+    // sum, then the running prefix) instead of being kept: 8 x 17 registers would leave two waves per SIMD.
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    ScanVal v[kScanItems];
     ScanVal sum = sv_zero();
-#pragma unroll
-    for (int k = 0; k < kScanItems; k++) {
-        v[k] = sv_load(src, cnt, base + k, n);
-        sum = sv_add(sum, v[k]);
-    }
+#pragma unroll 2
+    for (int k = 0; k < kScanItems; k++) sum = sv_add(sum, sv_load(src, cnt, base + k, n));
     ScanVal total;
     const ScanVal inc = block_inclusive_scan(sum, lds, total);
     ScanVal run = sv_add(tile_off[blockIdx.x], block_exclusive_from_inclusive(inc, excl));
-#pragma unroll
+#pragma unroll 2
     for (int k = 0; k < kScanItems; k++) {
         const int64_t i = base + k;
         if (i <= n) {  // entry n receives the grand totals
             S[i] = Moment{run.m.h, run.m.l, run.x.h, run.x.l, run.y.h, run.y.l, run.z.h, run.z.l};
             Pex[i] = run.c;
         }
-        run = sv_add(run, v[k]);
+        run = sv_add(run, sv_load(src, cnt, i, n));
     }
 }
 
@@ -667,8 +664,10 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     const bool take = active && geom;
     bool force = take;
     if (kGuard) force = take && (dist_sq > P.eps2);
+    // same association as the hand-scheduled loop, (G m / d) (1 / d^2): a body's sums must not depend on
+    // which of its visits went through this C++ form (that depends on the other bodies of its wave)
     const float inv = __builtin_amdgcn_rsqf(dist_sq);
-    const float f = force ? nd.gm * inv * inv * inv : 0.f;
+    const float f = force ? (nd.gm * inv) * (inv * inv) : 0.f;
     ax = fmaf(dx, f, ax);
     ay = fmaf(dy, f, ay);
     az = fmaf(dz, f, az);
@@ -1088,7 +1087,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ n
         bool take = hi < d2b;
         if (!take && lo < d2b) take = (hi == 0) || exact_take(off, b64);
         const float inv = __builtin_amdgcn_rsqf(d2);
-        const float f = take ? a.w * inv * inv * inv : 0.f;
+        const float f = take ? (a.w * inv) * (inv * inv) : 0.f;
         ax = fmaf(dx, f, ax); ay = fmaf(dy, f, ay); az = fmaf(dz, f, az);
         off = take ? __float_as_uint(b.y) : off + kNodeBytes;
     }

@@ -176,6 +176,14 @@ int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 
+/* Test / measurement hook for the device sort behind the octree build ("Morton-code octree build via
+ * device radix sort"; it replaces np.argsort of boids/flock.py:618 as well): sorts n (key, value) pairs
+ * given as HOST arrays by the low `bits` bits of the key (key_bytes 4 or 8), stable.  impl 0 = the
+ * hand-written gfx950 radix sort of csrc/radix.hip (the product path), 1 = rocPRIM (cross-check).
+ * *ms_per_sort = mean device time of `repeats` sorts after one untimed run. */
+int nbmi_debug_sort_pairs(int key_bytes, int64_t n, const void *keys, const uint32_t *values, void *keys_out,
+                          uint32_t *values_out, int bits, int impl, int repeats, double *ms_per_sort);
+
 #ifdef __cplusplus
 }
 #endif
