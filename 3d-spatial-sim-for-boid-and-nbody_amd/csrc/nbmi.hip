@@ -256,16 +256,19 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// K5: gather bodies into key order: fp32 {x,y,z,G*m} (walk / leaf data, and the input of the
-// moment prefix sums) and the low key word.
+// K5: gather bodies into key order: fp32 {x,y,z,G*m} (walk / leaf data), the same in float64 (input of
+// the moment prefix sums) and the low key word.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_gather(Bodies cur, const uint32_t *__restrict__ perm,
                                                    const uint64_t *__restrict__ key_lo, int64_t n, double G,
-                                                   float4 *__restrict__ posm_s, uint64_t *__restrict__ lo_s) {
+                                                   float4 *__restrict__ posm_s, double4 *__restrict__ p64_s,
+                                                   uint64_t *__restrict__ lo_s) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const uint32_t j = perm[r];
-    posm_s[r] = make_float4((float)cur.x[j], (float)cur.y[j], (float)cur.z[j], (float)(G * cur.m[j]));
+    const double x = cur.x[j], y = cur.y[j], z = cur.z[j], gm = G * cur.m[j];
+    posm_s[r] = make_float4((float)x, (float)y, (float)z, (float)gm);
+    p64_s[r] = make_double4(x, y, z, gm);  // float64 twin: input of the moment sums (coalesced there)
     lo_s[r] = key_lo[j];
 }
 
@@ -326,21 +329,18 @@ __device__ __forceinline__ ScanVal sv_zero() { return ScanVal{{0.0, 0.0}, {0.0, 
 __device__ __forceinline__ ScanVal sv_add(const ScanVal &a, const ScanVal &b) {
     return ScanVal{dd_add(a.m, b.m), dd_add(a.x, b.x), dd_add(a.y, b.y), dd_add(a.z, b.z), a.c + b.c};
 }
-// Where the sorted bodies' moments come from: the handle's own float64 state through the sort
-// permutation (single GPU and row-exchange shards), or fp32 records received from other ranks (run exchange).
+// Where the sorted bodies' moments come from: the float64 records k_gather wrote in key order (single GPU
+// and row-exchange shards), or fp32 records received from other ranks (run exchange).
 struct MomentSrc {
-    Bodies cur;                 // float64 state (perm != nullptr)
-    const uint32_t *perm;
-    const float4 *posm;         // fallback: fp32 {x,y,z,G m}
-    double G;
+    const double4 *p64;   // {x, y, z, G m} in key order, or nullptr
+    const float4 *posm;   // fallback: fp32 {x,y,z,G m}
 };
 __device__ __forceinline__ ScanVal sv_load(const MomentSrc &src, const int32_t *__restrict__ cnt, int64_t i, int64_t n) {
     if (i >= n) return sv_zero();
     double gm, x, y, z;
-    if (src.perm) {
-        const uint32_t j = src.perm[i];
-        gm = src.G * src.cur.m[j];
-        x = src.cur.x[j]; y = src.cur.y[j]; z = src.cur.z[j];
+    if (src.p64) {
+        const double4 q = src.p64[i];
+        x = q.x; y = q.y; z = q.z; gm = q.w;
     } else {
         const float4 p = src.posm[i];
         gm = (double)p.w; x = (double)p.x; y = (double)p.y; z = (double)p.z;
@@ -1395,6 +1395,7 @@ struct nbmi_sim {
     uint32_t *idx = nullptr, *perm = nullptr;
     int32_t *delta = nullptr, *cnt = nullptr, *Pex = nullptr;
     float4 *posm_s = nullptr;
+    double4 *p64_s = nullptr;  // float64 twin of posm_s (moment sums)
     Moment *S = nullptr;
     ScanVal *tile_sum = nullptr;
     Node *nodes = nullptr;
@@ -1506,7 +1507,7 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, s->idx, n);
     std::swap(s->perm, s->idx);  // the tie-fixed permutation is `perm` from here on; the old buffer takes the next step's indices
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
-    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->lo_s);
+    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->p64_s, s->lo_s);
     return 0;
 }
 
@@ -1517,7 +1518,7 @@ int enqueue_global_tree(nbmi_sim *s) {
     {
         const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
         // moments from the float64 state through the sort permutation; run exchange: from the fp32 records
-        const MomentSrc src{s->buf[s->curbuf], s->world > 0 ? nullptr : s->perm, s->t_posm, s->G};
+        const MomentSrc src{s->world > 0 ? nullptr : s->p64_s, s->t_posm};
         k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum);
         k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
         k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum, s->S, s->Pex);
@@ -1718,7 +1719,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
     if (s->method == NBMI_METHOD_BARNES_HUT) {
         s->node_capacity = node_rows_for(n);  // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N
         if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
-            dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
+            dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->p64_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
             dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
             dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->node_ref, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||

@@ -94,8 +94,9 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     __shared__ unsigned tile_off[kBins];        // first slot of the digit inside the reordered tile
     __shared__ unsigned glob_off[kBins];        // global slot of reordered slot q of digit d = glob_off[d] + q
     __shared__ unsigned wave_tot[kWaves];
+    // the reorder buffer is used twice, for the keys and then for the values (38 KB instead of 54 KB of LDS:
+    // four workgroups per CU instead of two)
     __shared__ K lds_k[kTile];
-    __shared__ uint32_t lds_v[kTile];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) s_tile = atomicAdd(&ctl->tile_ticket[pass], 1u);
@@ -201,26 +202,41 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     __syncthreads();
 
     // reorder inside the tile: digit runs, each in input order
+    unsigned slot[kItems / 2];  // two 16-bit slots per register
 #pragma unroll
     for (int i = 0; i < kItems; i++) {
         const int64_t idx = wave_base + i * 64 + lane;
+        unsigned q = 0;
         if (idx < n) {
             const unsigned d = digit_of(key[i], shift);
-            const unsigned q = tile_off[d] + cnt_w[w][d] + rank[i];
+            q = tile_off[d] + cnt_w[w][d] + rank[i];
             lds_k[q] = key[i];
-            lds_v[q] = val[i];
         }
+        if (i & 1) slot[i >> 1] |= q << 16; else slot[i >> 1] = q;
     }
     __syncthreads();
+    unsigned dst[kItems];
 #pragma unroll
     for (int i = 0; i < kItems; i++) {
         const int q = i * kThreads + t;
         if (q < valid_in_tile) {
             const K k = lds_k[q];
-            const unsigned dst = glob_off[digit_of(k, shift)] + (unsigned)q;
-            kout[dst] = k;
-            vout[dst] = lds_v[q];
+            dst[i] = glob_off[digit_of(k, shift)] + (unsigned)q;
+            kout[dst[i]] = k;
         }
+    }
+    __syncthreads();
+    uint32_t *lds_v = reinterpret_cast<uint32_t *>(lds_k);
+#pragma unroll
+    for (int i = 0; i < kItems; i++) {
+        const int64_t idx = wave_base + i * 64 + lane;
+        if (idx < n) lds_v[(slot[i >> 1] >> ((i & 1) * 16)) & 0xffffu] = val[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kItems; i++) {
+        const int q = i * kThreads + t;
+        if (q < valid_in_tile) vout[dst[i]] = lds_v[q];
     }
 }
 
