@@ -37,13 +37,13 @@ hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit,
                               int end_bit, hipStream_t s);
 
-// the hand-written radix sort (radix.hip): keys of `bits` significant bits, stable, ping-pong inside `temp`
+// the hand-written radix sort (radix.hip): by key bits [begin_bit, end_bit), stable, ping-pong inside `temp`
 size_t radix_temp_bytes_u64(size_t n, int bits);
 size_t radix_temp_bytes_u32(size_t n, int bits);
 hipError_t radix_sort_pairs_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
-                                uint32_t *vout, size_t n, int bits, hipStream_t s);
+                                uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 hipError_t radix_sort_pairs_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                                uint32_t *vout, size_t n, int bits, hipStream_t s);
+                                uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 hipError_t radix_error_word(const void *temp, unsigned *out, hipStream_t s);
 
 // One body of a key-sorted run as it travels between GPUs (multi-GPU run exchange): the two

@@ -96,6 +96,8 @@ struct TreeInfo {
     long long num_nodes;             // N + number of internal cells (reference numbering)
     int max_level;                   // deepest leaf level
     int error;                       // 1 = node capacity exceeded
+    int max_run;                     // longest run of bodies equal in the radix-sorted key prefix (> 64 only)
+    int pad0;
     unsigned long long wave_visits, lane_visits, lane_accepts;
     unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
     unsigned long long jumps;        // cursor moves other than to the next node in memory
@@ -203,56 +205,69 @@ __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, c
 }
 
 // ---------------------------------------------------------------------------------------
-// K4: order runs of equal key_hi by key_lo (bodies that share all 21 upper digits: none at 1 M bodies,
-// pairs at 10 M; thousands inside one level-21 cell once an escaper has inflated the root cube).
-// One thread per body; a body inside a run finds the run's ends by galloping + binary search on the
-// sorted keys and its place by counting the run's members that sort before it - L reads per member,
-// all members in parallel, so a run of 10^5 bodies costs about a millisecond instead of the minutes a
-// one-thread insertion sort would take.  Ties on both words keep the input order (the sort is stable
-// and idx ascends), like the reference's insertion order.  Writes the final permutation to `out`.
+// K4: finish the order.  The radix sort only looks at the top `sort_bits` bits of the upper key word
+// (13 levels by default: 5 digit passes instead of 8); bodies that agree on those bits form a run - none or
+// pairs in the bench systems, thousands inside one cell once an escaper has inflated the root cube - and
+// are put in order of their full 126-bit key here.  One thread per body; a body inside a run finds the
+// run's ends by galloping + binary search on the sorted prefixes and its place by counting the run's
+// members that sort before it: L reads per member, all members in parallel, so a run of 10^5 bodies costs
+// about a millisecond (a one-thread insertion sort of it took minutes).  Equal keys keep the input order
+// (the sort is stable and idx ascends), like the reference's insertion order.  Writes the final
+// permutation and the fully sorted upper words; the longest run is recorded so that the host can widen
+// the sorted prefix for the following steps.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
-                                                   const uint32_t *__restrict__ perm, uint32_t *__restrict__ out, int64_t n) {
+                                                   const uint32_t *__restrict__ perm, int shift,
+                                                   uint32_t *__restrict__ perm_out, uint64_t *__restrict__ hi_out, int64_t n,
+                                                   TreeInfo *info) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    const uint64_t h = hi_s[r];
+    const uint64_t h = hi_s[r], hp = h >> shift;
     const uint32_t p = perm[r];
-    const bool tie = (r + 1 < n && hi_s[r + 1] == h) || (r > 0 && hi_s[r - 1] == h);
+    const bool tie = (r + 1 < n && (hi_s[r + 1] >> shift) == hp) || (r > 0 && (hi_s[r - 1] >> shift) == hp);
     if (!tie) {
-        out[r] = p;
+        perm_out[r] = p;
+        hi_out[r] = h;
         return;
     }
-    // run = [s, e): first / one past the last rank with this key_hi
+    // run = [s, e): first / one past the last rank with this prefix
     int64_t lo_ok = r, lo_bad, step = 1;
     for (;;) {  // backwards
         const int64_t t = r - step;
         if (t < 0) { lo_bad = -1; break; }
-        if (hi_s[t] == h) { lo_ok = t; step <<= 1; } else { lo_bad = t; break; }
+        if ((hi_s[t] >> shift) == hp) { lo_ok = t; step <<= 1; } else { lo_bad = t; break; }
     }
     while (lo_ok - lo_bad > 1) {
         const int64_t mid = lo_bad + ((lo_ok - lo_bad) >> 1);
-        if (hi_s[mid] == h) lo_ok = mid; else lo_bad = mid;
+        if ((hi_s[mid] >> shift) == hp) lo_ok = mid; else lo_bad = mid;
     }
     int64_t hi_ok = r, hi_bad;
     step = 1;
     for (;;) {  // forwards
         const int64_t t = r + step;
         if (t >= n) { hi_bad = n; break; }
-        if (hi_s[t] == h) { hi_ok = t; step <<= 1; } else { hi_bad = t; break; }
+        if ((hi_s[t] >> shift) == hp) { hi_ok = t; step <<= 1; } else { hi_bad = t; break; }
     }
     while (hi_bad - hi_ok > 1) {
         const int64_t mid = hi_ok + ((hi_bad - hi_ok) >> 1);
-        if (hi_s[mid] == h) hi_ok = mid; else hi_bad = mid;
+        if ((hi_s[mid] >> shift) == hp) hi_ok = mid; else hi_bad = mid;
     }
     const int64_t s = lo_ok, e = hi_bad;
+    if (r == s && e - s > 64) atomicMax(&info->max_run, (int)(e - s < 0x7fffffff ? e - s : 0x7fffffff));
     const uint64_t la = key_lo[p];
     int64_t before = 0;
     for (int64_t j = s; j < e; j++) {
+        const uint64_t hj = hi_s[j];
         const uint32_t pj = perm[j];
-        const uint64_t lj = key_lo[pj];
-        before += (lj < la || (lj == la && pj < p)) ? 1 : 0;
+        if (hj != h) {
+            before += hj < h ? 1 : 0;
+        } else {
+            const uint64_t lj = key_lo[pj];
+            before += (lj < la || (lj == la && pj < p)) ? 1 : 0;
+        }
     }
-    out[s + before] = p;
+    perm_out[s + before] = p;
+    hi_out[s + before] = h;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1425,6 +1440,7 @@ struct nbmi_sim {
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
+    int sort_bits = 40;  // upper-word bits the radix sort looks at (NBMI_SORT_BITS); widened when long runs show up
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
@@ -1502,10 +1518,16 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     Bodies cur = s->buf[s->curbuf];
     k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
+    // radix sort on the top sort_bits bits of the upper word, then the tie-fix completes the 126-bit order
+    const int shift = 63 - s->sort_bits;
     NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
-                                            (size_t)n, 0, 63, st));
-    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, s->idx, n);
-    std::swap(s->perm, s->idx);  // the tie-fixed permutation is `perm` from here on; the old buffer takes the next step's indices
+                                            (size_t)n, shift, 63, st));
+    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, shift, s->idx, s->key_hi, n, s->info);
+    // the finished permutation / sorted upper words are `perm` / `hi_s` from here on; the old buffers take
+    // the next step's indices and keys
+    std::swap(s->perm, s->idx);
+    std::swap(s->hi_s, s->key_hi);
+    if (s->world == 0) s->t_hi = s->hi_s;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
     k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->p64_s, s->lo_s);
     return 0;
@@ -1644,6 +1666,11 @@ int check_device_error(nbmi_sim *s) {
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (h.max_run > 4096 && s->sort_bits < 63) {
+        // many bodies agree on the sorted prefix (a dense core inside one level-13 cell): the tie-fix did the
+        // rest correctly but at L reads per member - sort on more bits from the next step on
+        s->sort_bits = s->sort_bits + 8 < 63 ? s->sort_bits + 8 : 63;
+    }
     if (h.error || h.sticky_error) {
         // reported once: clear the sticky word so the handle can go on after nbmi_set_state / a retry.  The
         // bodies stand at the last step that completed (the walk froze them while the word was set).
@@ -1697,6 +1724,10 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
+    if (const char *e = getenv("NBMI_SORT_BITS")) {
+        const int b = atoi(e);
+        if (b >= 8 && b <= 63) s->sort_bits = b;
+    }
     if (const char *e = getenv("NBMI_WALK_BLOCK")) {
         const int b = atoi(e);
         if (b == 64 || b == 128 || b == 256) s->walk_block = b;

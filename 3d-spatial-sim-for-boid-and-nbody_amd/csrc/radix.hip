@@ -253,7 +253,8 @@ size_t temp_bytes(size_t n, int bits) {
 
 template <typename K>
 hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout,
-                      size_t n, int bits, hipStream_t st) {
+                      size_t n, int begin_bit, int end_bit, hipStream_t st) {
+    const int bits = end_bit - begin_bit;
     if (n == 0) return hipSuccess;
     if (n > (size_t)kValueMask) return hipErrorInvalidValue;  // counts travel in 30 bits
     const int passes = passes_for(bits);
@@ -269,7 +270,7 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
     if (e != hipSuccess) return e;
     int hb = (int)((n + kThreads * 8 - 1) / (kThreads * 8));
     if (hb > 1024) hb = 1024;
-    k_radix_hist<K><<<hb, kThreads, 0, st>>>(kin, (int64_t)n, passes, 0, ctl);
+    k_radix_hist<K><<<hb, kThreads, 0, st>>>(kin, (int64_t)n, passes, begin_bit, ctl);
     k_radix_offsets<<<passes, kBins, 0, st>>>(ctl);
     // ping-pong so that the last pass writes the caller's output: ... -> tmp -> out
     const K *ksrc = kin;
@@ -278,7 +279,7 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         K *kdst = to_out ? kout : ktmp;
         uint32_t *vdst = to_out ? vout : vtmp;
-        k_radix_pass<K><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, p * kRadixBits, p, ctl,
+        k_radix_pass<K><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, begin_bit + p * kRadixBits, p, ctl,
                                                          status + (size_t)p * tiles * kBins);
         ksrc = kdst;
         vsrc = vdst;
@@ -292,12 +293,12 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
 size_t radix_temp_bytes_u64(size_t n, int bits) { return temp_bytes<uint64_t>(n, bits); }
 size_t radix_temp_bytes_u32(size_t n, int bits) { return temp_bytes<uint32_t>(n, bits); }
 hipError_t radix_sort_pairs_u64(void *temp, size_t temp_size, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
-                                uint32_t *vout, size_t n, int bits, hipStream_t s) {
-    return sort_pairs<uint64_t>(temp, temp_size, kin, kout, vin, vout, n, bits, s);
+                                uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s) {
+    return sort_pairs<uint64_t>(temp, temp_size, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 hipError_t radix_sort_pairs_u32(void *temp, size_t temp_size, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                                uint32_t *vout, size_t n, int bits, hipStream_t s) {
-    return sort_pairs<uint32_t>(temp, temp_size, kin, kout, vin, vout, n, bits, s);
+                                uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s) {
+    return sort_pairs<uint32_t>(temp, temp_size, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 // 1 if a look-back of the last sort on this temp buffer timed out (never observed; the spin is bounded so
 // that a lost status word cannot hang the GPU)

@@ -43,9 +43,9 @@ size_t sort_pairs_temp_bytes(size_t n, int begin_bit, int end_bit) {
 hipError_t sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit,
                               hipStream_t s) {
-    if (use_rocprim() || begin_bit != 0)
+    if (use_rocprim())
         return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
-    return radix_sort_pairs_u64(temp, temp_bytes, kin, kout, vin, vout, n, end_bit, s);
+    return radix_sort_pairs_u64(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 
 size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit) {
@@ -56,9 +56,9 @@ size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit) {
 hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit,
                               hipStream_t s) {
-    if (use_rocprim() || begin_bit != 0)
+    if (use_rocprim())
         return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
-    return radix_sort_pairs_u32(temp, temp_bytes, kin, kout, vin, vout, n, end_bit, s);
+    return radix_sort_pairs_u32(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 
 }  // namespace nbmi
@@ -95,12 +95,12 @@ extern "C" int nbmi_debug_sort_pairs(int key_bytes, int64_t n, const void *keys,
             e = impl ? rocprim::radix_sort_pairs(tmp, tb, (const uint64_t *)dk, (uint64_t *)dko, (const uint32_t *)dv,
                                                  (uint32_t *)dvo, (size_t)n, 0, bits, st)
                      : nbmi::radix_sort_pairs_u64(tmp, tb, (const uint64_t *)dk, (uint64_t *)dko, (const uint32_t *)dv,
-                                                  (uint32_t *)dvo, (size_t)n, bits, st);
+                                                  (uint32_t *)dvo, (size_t)n, 0, bits, st);
         } else {
             e = impl ? rocprim::radix_sort_pairs(tmp, tb, (const uint32_t *)dk, (uint32_t *)dko, (const uint32_t *)dv,
                                                  (uint32_t *)dvo, (size_t)n, 0, bits, st)
                      : nbmi::radix_sort_pairs_u32(tmp, tb, (const uint32_t *)dk, (uint32_t *)dko, (const uint32_t *)dv,
-                                                  (uint32_t *)dvo, (size_t)n, bits, st);
+                                                  (uint32_t *)dvo, (size_t)n, 0, bits, st);
         }
         if (e != hipSuccess) fail("sort", e);
     }
