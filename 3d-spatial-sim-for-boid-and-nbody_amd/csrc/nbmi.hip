@@ -94,6 +94,7 @@ struct TreeInfo {
     unsigned long long maxabs_bits;  // max |coordinate| (non-negative double bit pattern)
     double bounds;                   // root half size
     long long num_nodes;             // N + number of internal cells (reference numbering)
+    long long walk_nodes;            // nodes the walk covers: num_nodes, plus received trees in owner mode
     int max_level;                   // deepest leaf level
     int error;                       // 1 = node capacity exceeded
     int max_run;                     // longest run of bodies equal in the radix-sorted key prefix (> 64 only)
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
         const int64_t total = n + (int64_t)Pex[n];
         if (r == 0) {
             info->num_nodes = total;
+            info->walk_nodes = total;
             info->band2 = 2u * band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
         }
         if (total + 1 > capacity) {  // + 1: the sentinel
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
     const bool valid = rank < P.rank_end;
     const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
-    const unsigned nn = frozen ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);  // end offset
+    const unsigned nn = frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeBytes);  // end offset
 
     WalkCtx C;
     C.nodes = nodes;
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     if (!kCount && !kGuard) {
         if (nn && P.pair) {
             // two cursors: [0, mid) and [mid, nn); the second needs the lanes' state at mid (seek)
-            const unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->num_nodes / 2) * kNodeBytes);
+            const unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->walk_nodes / 2) * kNodeBytes);
             // (each half sums into its own accumulator, added at the end: a body's result must not depend
             // on how the two cursors' visits interleave, i.e. on the other bodies of its group)
             unsigned resume2 = resume;
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     const int64_t rank = P.rank_begin + (int64_t)lb * 64 + lane;
     const bool valid = rank < P.rank_end;
     const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
-    const int64_t num_nodes = frozen ? 0 : info_in->num_nodes;
+    const int64_t num_nodes = frozen ? 0 : info_in->walk_nodes;
 
     WalkCtx C;
     C.nodes = nodes;
@@ -1084,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ n
     const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
     if (rank >= P.rank_end) return;
     const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
-    const unsigned nn = frozen ? 0u : ((unsigned)info_in->num_nodes * kNodeBytes);
+    const unsigned nn = frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeBytes);
     const unsigned band2 = info_in->band2;
     const float4 p = posm_s[rank];
     const uint32_t j = perm[rank];
@@ -1193,7 +1195,8 @@ __global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ po
 // colour ramp (simulation.py:320-400 == gpu_backend.py:259-325), float64 maths, f32 stores,
 // rows written in the caller's body order.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_colors(Bodies cur, int64_t n, double max_speed, float *__restrict__ colors) {
+__global__ __launch_bounds__(kBlock) void k_colors(Bodies cur, int64_t n, double max_speed, bool by_rank,
+                                                   float *__restrict__ colors) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const double vx = cur.vx[r], vy = cur.vy[r], vz = cur.vz[r];
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(kBlock) void k_colors(Bodies cur, int64_t n, double
         s = (t - 0.99) / 0.01;
         cr = 1.0; cg = __dsub_rn(0.5, __dmul_rn(0.5, s)); cb = 0.0;
     }
-    const int64_t o = 3 * (int64_t)cur.id[r];
+    const int64_t o = 3 * (by_rank ? r : (int64_t)cur.id[r]);  // owner mode: rows stay in rank order
     colors[o] = (float)cr; colors[o + 1] = (float)cg; colors[o + 2] = (float)cb;
 }
 
@@ -1240,7 +1243,7 @@ __global__ __launch_bounds__(kBlock) void k_unperm3_f32(const double *__restrict
                                                         int64_t n, float *__restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    const int64_t o = 3 * (int64_t)id[r];
+    const int64_t o = 3 * (id ? (int64_t)id[r] : r);  // owner mode: rows stay in rank order
     out[o] = (float)a[r]; out[o + 1] = (float)b[r]; out[o + 2] = (float)c[r];
 }
 __global__ __launch_bounds__(kBlock) void k_unperm3_f64(const double *__restrict__ a, const double *__restrict__ b,
@@ -1248,7 +1251,7 @@ __global__ __launch_bounds__(kBlock) void k_unperm3_f64(const double *__restrict
                                                         int64_t n, double *__restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
-    const int64_t o = 3 * (int64_t)id[r];
+    const int64_t o = 3 * (id ? (int64_t)id[r] : r);
     out[o] = a[r]; out[o + 1] = b[r]; out[o + 2] = c[r];
 }
 __global__ __launch_bounds__(kBlock) void k_split_state(const double *__restrict__ pos, const double *__restrict__ vel,
@@ -1316,84 +1319,280 @@ inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
 
+namespace {
 // =========================================================================================
-// multi-GPU run exchange: a rank's key-sorted bodies as 32-byte records and back to the arrays
-// the tree kernels read.  Padding records carry the all-ones key so they merge to the very end.
+// Multi-GPU stage 2 ("owner mode"): every rank OWNS the bodies of one octant-key range, builds the octree
+// of its own bodies inside the GLOBAL root cube and receives from every other rank only the part of that
+// rank's tree its own bodies can open (a locally essential tree).  Kernels for: the key samples the
+// splitters come from, the destination of every body, the body bounding box, and the extraction /
+// appending of locally essential trees.  The collectives themselves are the host framework's (RCCL).
 // =========================================================================================
-using nbmi::RunRec;
-__global__ __launch_bounds__(kBlock) void k_pack_run(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
-                                                     const float4 *__restrict__ posm_s, int64_t n, int64_t rows,
-                                                     RunRec *__restrict__ out) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r >= rows) return;
-    RunRec q;
-    if (r < n) {
-        const float4 p = posm_s[r];
-        q.hi = hi_s[r]; q.lo = lo_s[r];
-        q.x = p.x; q.y = p.y; q.z = p.z; q.gm = p.w;
-    } else {
-        q.hi = ~0ull; q.lo = ~0ull;
-        q.x = q.y = q.z = q.gm = 0.f;
-    }
-    out[r] = q;
+constexpr int kMaxWorld = 64;
+constexpr int kSampleCap = 4096;  // world x samples_per_rank, sorted in LDS by one workgroup
+
+// regular samples of the (nearly key-ordered) local keys
+__global__ __launch_bounds__(kBlock) void k_key_samples(const uint64_t *__restrict__ key_hi, int64_t n, int nsamples,
+                                                        uint64_t *__restrict__ out) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nsamples) return;
+    // an empty rank contributes nothing: its samples sort to the very end and are ignored (all ones)
+    out[k] = n > 0 ? key_hi[(int64_t)((2 * (int64_t)k + 1) * n / (2 * (int64_t)nsamples))] : ~0ull;
 }
 
-// Merge of the `world` gathered runs by ranking: a record's position in the merged order is its
-// index in its own run plus, for every other run, the number of records that sort before it (ties:
-// lower run first, so the order is total and every rank unique).  All `world - 1` binary searches
-// of a thread advance together (independent loads in flight), and the record is scattered straight
-// into the arrays the tree kernels read.  Padding records (all-ones keys) rank after every real
-// one and are dropped; `nt` real records must come out, else info->error = 2.
-constexpr int kPeers = 8;  // searches interleaved per pass
-__global__ __launch_bounds__(kBlock) void k_merge_ranks(const RunRec *__restrict__ runs, int world, int R, int64_t nt,
-                                                        int steps, uint64_t *__restrict__ hi, uint64_t *__restrict__ lo,
-                                                        float4 *__restrict__ posm, TreeInfo *info) {
-    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (int64_t)world * R) return;
-    const int a = (int)(t / R);
-    const int i = (int)(t - (int64_t)a * R);
-    const RunRec me = runs[t];
-    if (me.hi == ~0ull && me.lo == ~0ull) return;
-    int64_t rank = i;
-    for (int b0 = 0; b0 < world; b0 += kPeers) {
-        int first[kPeers], len[kPeers];
-#pragma unroll
-        for (int k = 0; k < kPeers; k++) {
-            first[k] = 0;
-            len[k] = (b0 + k < world && b0 + k != a) ? R : 0;
-        }
-        for (int s = 0; s < steps; s++) {
-            ulonglong2 key[kPeers];
-#pragma unroll
-            for (int k = 0; k < kPeers; k++) {
-                int mid = first[k] + (len[k] >> 1);
-                mid = mid < R ? mid : R - 1;
-                const int b = b0 + k < world ? b0 + k : a;
-                key[k] = *reinterpret_cast<const ulonglong2 *>(&runs[(int64_t)b * R + mid]);
+// one workgroup: bitonic sort of all ranks' samples in LDS, then world - 1 splitters at equal quantiles of the
+// valid samples.  Rank j owns the keys in [split[j-1], split[j]).
+__global__ __launch_bounds__(kBlock) void k_splitters(const uint64_t *__restrict__ samples, int total, int world,
+                                                      uint64_t *__restrict__ split) {
+    __shared__ uint64_t a[kSampleCap];
+    for (int i = threadIdx.x; i < kSampleCap; i += kBlock) a[i] = i < total ? samples[i] : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= kSampleCap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kSampleCap; i += kBlock) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint64_t x = a[i], y = a[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[l] = x; }
+                }
             }
-#pragma unroll
-            for (int k = 0; k < kPeers; k++) {
-                const int half = len[k] >> 1;
-                const bool key_lt_me = key[k].x < me.hi || (key[k].x == me.hi && key[k].y < me.lo);
-                const bool key_eq_me = key[k].x == me.hi && key[k].y == me.lo;
-                // runs before mine count their records <= me, runs after mine those < me
-                const bool before = (key_lt_me || (key_eq_me && b0 + k < a)) && len[k] > 0;
-                first[k] = before ? first[k] + half + 1 : first[k];
-                len[k] = before ? len[k] - half - 1 : half;
-            }
+            __syncthreads();
         }
-#pragma unroll
-        for (int k = 0; k < kPeers; k++) rank += first[k];
     }
-    if (rank >= nt) {
-        info->error = 2;
-        info->sticky_error = 2;
-        return;
+    __shared__ int valid;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = total;  // first all-ones entry
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] == ~0ull) hi = mid; else lo = mid + 1; }
+        valid = lo;
     }
-    hi[rank] = me.hi;
-    lo[rank] = me.lo;
-    posm[rank] = make_float4(me.x, me.y, me.z, me.gm);
+    __syncthreads();
+    for (int j = threadIdx.x; j < world - 1; j += kBlock)
+        split[j] = valid > 0 ? a[(int)((int64_t)(j + 1) * valid / world)] : ~0ull;
 }
+
+// destination rank of every body: number of splitters <= its upper key word (bodies that agree on all 21
+// upper digits always travel together)
+__global__ __launch_bounds__(kBlock) void k_dest(const uint64_t *__restrict__ key_hi, int64_t n, const uint64_t *__restrict__ split,
+                                                 int world, uint32_t *__restrict__ dest, uint32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key_hi[i];
+    int lo = 0, hi = world - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (split[mid] <= k) lo = mid + 1; else hi = mid; }
+    dest[i] = (uint32_t)lo;
+    idx[i] = (uint32_t)i;
+}
+
+// counts per destination from the destination-sorted array
+__global__ void k_dest_counts(const uint32_t *__restrict__ dest_s, int64_t n, int world, int64_t *__restrict__ counts) {
+    const int j = threadIdx.x;
+    if (j >= world) return;
+    auto lower = [&](uint32_t v) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (dest_s[mid] < v) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    counts[j] = lower((uint32_t)j + 1u) - lower((uint32_t)j);
+}
+
+// rows {x,y,z,vx,vy,vz,m,id} in the order `order` (grouped by destination, input order inside a group)
+__global__ __launch_bounds__(kBlock) void k_pack_rows_perm(Bodies cur, const uint32_t *__restrict__ order, int64_t n,
+                                                           double *__restrict__ rows) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t r = order[k];
+    double *o = rows + 8 * k;
+    o[0] = cur.x[r]; o[1] = cur.y[r]; o[2] = cur.z[r];
+    o[3] = cur.vx[r]; o[4] = cur.vy[r]; o[5] = cur.vz[r];
+    o[6] = cur.m[r]; o[7] = (double)cur.id[r];
+}
+
+// bounding box of the bodies: per-block partials, then one block
+__global__ __launch_bounds__(kBlock) void k_bbox_blocks(const double *__restrict__ x, const double *__restrict__ y,
+                                                        const double *__restrict__ z, int64_t n, double *__restrict__ part) {
+    __shared__ double red[6][kBlock / 64];
+    double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double a = x[i], b = y[i], c = z[i];
+        v[0] = fmin(v[0], a); v[1] = fmin(v[1], b); v[2] = fmin(v[2], c);
+        v[3] = fmax(v[3], a); v[4] = fmax(v[4], b); v[5] = fmax(v[5], c);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double t = __shfl_xor(v[k], o);
+            v[k] = k < 3 ? fmin(v[k], t) : fmax(v[k], t);
+        }
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        double r = red[k][0];
+        for (int w = 1; w < kBlock / 64; w++) r = k < 3 ? fmin(r, red[k][w]) : fmax(r, red[k][w]);
+        part[6 * blockIdx.x + k] = r;
+    }
+}
+__global__ void k_bbox_final(const double *__restrict__ part, int blocks, double *__restrict__ out6) {
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    double r = part[k];
+    for (int b = 1; b < blocks; b++) r = k < 3 ? fmin(r, part[6 * b + k]) : fmax(r, part[6 * b + k]);
+    out6[k] = r;
+}
+
+// ---- plain int32 exclusive scan (three phases, like the moment scan) ---------------------------
+__global__ __launch_bounds__(kBlock) void k_iscan_reduce(const int32_t *__restrict__ in, int64_t n, int32_t *__restrict__ tile_sum) {
+    __shared__ int red[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+        acc += i < n ? in[i] : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kBlock / 64; w++) t += red[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_iscan_tiles(int32_t *__restrict__ tile_sum, int64_t ntiles) {
+    __shared__ int wsum[kBlock / 64];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < ntiles; base += kBlock) {
+        const int64_t i = base + threadIdx.x;
+        const int own = i < ntiles ? tile_sum[i] : 0;
+        int v = own;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v += o;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int off = carry_s;
+        for (int k = 0; k < w; k++) off += wsum[k];
+        if (i < ntiles) tile_sum[i] = off + v - own;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = off + v;
+        __syncthreads();
+    }
+}
+// out[i] = sum of in[0..i); entry n receives the total
+__global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restrict__ in, int64_t n, const int32_t *__restrict__ tile_off,
+                                                        int32_t *__restrict__ out) {
+    __shared__ int wsum[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int v[kScanItems], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { v[k] = base + k < n ? in[base + k] : 0; sum += v[k]; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int run = tile_off[blockIdx.x] + inc - sum;
+    for (int k = 0; k < w; k++) run += wsum[k];
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) {
+        if (base + k <= n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- locally essential tree -----------------------------------------------------------------
+// A cell can only be opened by a body of another rank if the opening test can fail somewhere in that rank's
+// bounding box; if it cannot (for any other rank), nobody else ever looks below it and its subtree stays
+// home.  Conservative by a 1e-9 margin on both sides of the float64 test.  diff[] marks the dropped
+// pre-order ranges (+1 at the first node of the subtree, -1 behind it): a node is kept iff the running sum
+// over diff up to and including it is zero.
+__global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
+                                                     int64_t num_nodes, const double *__restrict__ boxes, int world, int me,
+                                                     double theta, double eps2, int32_t *__restrict__ diff) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_nodes) return;
+    const Node nd = nodes[i];
+    if (__float_as_int(nd.s2t) == 0) return;  // a leaf: nothing below it
+    const Node64 c = n64[i];
+    const double size = c.hs * 2.0;
+    bool needed = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
+    const double thr = needed ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
+    for (int j = 0; j < world && !needed; j++) {
+        if (j == me) continue;
+        const double *b = boxes + 6 * j;
+        if (!(b[0] <= b[3])) continue;  // that rank owns nothing
+        const double dx = fmax(0.0, fmax(b[0] - c.cx, c.cx - b[3]));
+        const double dy = fmax(0.0, fmax(b[1] - c.cy, c.cy - b[4]));
+        const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
+        const double d2 = (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9);
+        if (d2 <= thr) needed = true;  // some point of the box may fail "size / dist < theta"
+    }
+    if (!needed) {
+        const int64_t nx = nd.next_off / kNodeBytes;
+        if (nx > i + 1) {
+            atomicAdd(&diff[i + 1], 1);
+            atomicAdd(&diff[nx], -1);
+        }
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_let_keep(const int32_t *__restrict__ diff, const int32_t *__restrict__ diff_ex,
+                                                     int64_t num_nodes, int32_t *__restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < num_nodes) keep[i] = (diff_ex[i] + diff[i]) == 0 ? 1 : 0;
+}
+// kept nodes move to their new index; links are re-based to the compacted numbering (a kept node's
+// successor is always kept: it hangs off one of the node's own ancestors)
+__global__ __launch_bounds__(kBlock) void k_let_compact(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
+                                                        const int32_t *__restrict__ keep, const int32_t *__restrict__ newidx,
+                                                        int64_t num_nodes, int64_t capacity, Node *__restrict__ out_nodes,
+                                                        Node64 *__restrict__ out_n64) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_nodes || !keep[i]) return;
+    const int64_t j = newidx[i];
+    if (j >= capacity) return;  // reported through the count
+    Node nd = nodes[i];
+    const int64_t nx = nd.next_off / kNodeBytes;
+    nd.next_off = (unsigned)newidx[nx] * kNodeBytes;
+    out_nodes[j] = nd;
+    out_n64[j] = n64[i];
+}
+// a received tree goes behind the trees already in the walk array: links shift by the base
+__global__ __launch_bounds__(kBlock) void k_let_append(const Node *__restrict__ src, const Node64 *__restrict__ src64, int64_t count,
+                                                       int64_t base, Node *__restrict__ nodes, Node64 *__restrict__ n64) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    Node nd = src[k];
+    nd.next_off += (unsigned)base * kNodeBytes;
+    nodes[base + k] = nd;
+    n64[base + k] = src64[k];
+}
+__global__ void k_let_finish(Node *__restrict__ nodes, int64_t total, TreeInfo *info) {
+    Node sn;
+    sn.cx = sn.cy = sn.cz = 1.0e30f;
+    sn.gm = 0.f; sn.s2t = 0.f;
+    sn.next_off = (unsigned)total * kNodeBytes;
+    nodes[total] = sn;
+    info->walk_nodes = total;
+}
+__global__ void k_copy_ids(const int32_t *__restrict__ ids, int32_t *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = ids[i];
+}
+
+}  // namespace
 
 // =========================================================================================
 // handle
@@ -1420,7 +1619,8 @@ struct nbmi_sim {
     int32_t *node_ref = nullptr;  // first body (sorted rank) of every node; queries only
     int32_t *cell_r = nullptr;  // internal-cell list: first body and level
     uint8_t *cell_lev = nullptr;
-    int64_t node_capacity = 0;
+    int64_t node_capacity = 0;   // rows of the walk array (own tree + received trees)
+    int64_t own_node_rows = 0;   // rows the handle's own tree may use
     TreeInfo *info = nullptr;  // device
     void *tmp_sort = nullptr;
     size_t tmp_sort_bytes = 0;
@@ -1429,12 +1629,21 @@ struct nbmi_sim {
     bool tree_valid = false;
     int64_t shard_begin = 0, shard_end = 0;
     bool exchange_sync = true;  // export / import block the host (false: the caller orders streams itself)
-    // octree inputs in key order.  Normally the handle's own sorted arrays (nt == n); with the run
-    // exchange enabled, the merge of every rank's run (nt = bodies of the whole system).
+    // octree inputs in key order: the handle's own sorted arrays (nt == n)
     int64_t nt = 0;
     uint64_t *t_hi = nullptr, *t_lo = nullptr;
     float4 *t_posm = nullptr;
-    int world = 0;  // > 0: run exchange enabled
+    // owner mode (multi-GPU stage 2): this handle holds the bodies of one octant-key range
+    bool owner = false;
+    int world = 0, rank = 0;
+    int64_t cap = 0;            // body capacity (0: exactly n)
+    int64_t let_capacity = 0;   // rows of one locally essential tree in the exchange buffers
+    int64_t node_extra = 0;     // node rows reserved behind the own tree for received trees
+    uint64_t *let_split = nullptr;
+    uint32_t *let_dest = nullptr, *let_dest_s = nullptr, *let_order = nullptr;
+    int64_t *let_counts = nullptr;
+    double *let_bbox = nullptr;
+    int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr;
     // render-side reduction scratch (nbmi_visible_points), allocated on first use
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
@@ -1527,7 +1736,7 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     // the next step's indices and keys
     std::swap(s->perm, s->idx);
     std::swap(s->hi_s, s->key_hi);
-    if (s->world == 0) s->t_hi = s->hi_s;
+    s->t_hi = s->hi_s;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
     k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->p64_s, s->lo_s);
     return 0;
@@ -1540,18 +1749,18 @@ int enqueue_global_tree(nbmi_sim *s) {
     {
         const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
         // moments from the float64 state through the sort permutation; run exchange: from the fp32 records
-        const MomentSrc src{s->world > 0 ? nullptr : s->p64_s, s->t_posm};
+        const MomentSrc src{s->p64_s, s->t_posm};
         k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum);
         k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
         k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum, s->S, s->Pex);
     }
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
-    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->node_capacity, s->nodes,
+    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->own_node_rows, s->nodes,
                                                  s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->softening, s->info);
     // one thread per internal cell; the count lives on the device, so launch for the row budget
-    k_emit_cells<<<nblocks(s->node_capacity - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
-                                                                  n, s->softening, inv_theta2, s->node_capacity, s->nodes,
+    k_emit_cells<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
+                                                                  n, s->softening, inv_theta2, s->own_node_rows, s->nodes,
                                                                   s->nodes64, s->node_level, s->node_ref, s->info);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1559,8 +1768,8 @@ int enqueue_global_tree(nbmi_sim *s) {
 
 // Single-GPU build: the tree over the handle's own bodies.
 int enqueue_tree(nbmi_sim *s, int ev_base) {
-    if (s->world > 0) {
-        nbmi::set_error("this handle is in run-exchange mode: use the nbmi_exchange_* calls");
+    if (s->owner) {
+        nbmi::set_error("this handle is in owner mode: use the nbmi_owner_* calls");
         return NBMI_ERR_ARG;
     }
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
@@ -1599,7 +1808,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     // fastest or within 5 % of it; beyond ~280 k bodies the one-wave walk wins
     int parts = 1;
     while (parts < 16 && tree_groups <= 4300 && tree_groups * parts * 2 <= s->split_max_waves) parts *= 2;
-    if (integrate && !guard && s->world == 0 && parts > 1) {
+    if (integrate && !guard && parts > 1) {
 #define NBMI_SPLIT(KV) \
     k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P)
         if (parts == 2) NBMI_SPLIT(2);
@@ -1679,10 +1888,6 @@ int check_device_error(nbmi_sim *s) {
         NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
         s->tree_valid = false;
     }
-    if (h.error == 2 || h.sticky_error == 2) {
-        nbmi::set_error("run exchange: the gathered runs do not hold the %lld bodies announced", (long long)s->nt);
-        return NBMI_ERR_ARG;
-    }
     if (h.error || h.sticky_error) {
         nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference); the "
                         "bodies were not advanced from that step on",
@@ -1736,27 +1941,32 @@ static void read_env_knobs(nbmi_sim *s) {
 
 static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const double *mass) {
     const int64_t n = s->n;
+    const int64_t c = s->cap > n ? s->cap : n;  // rows allocated (owner mode keeps head room for immigrants)
     NBMI_HIP_CHECK(hipSetDevice(s->device));
     NBMI_HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (auto &e : s->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
-    if (alloc_bodies(s, &s->buf[0], n) || alloc_bodies(s, &s->buf[1], n)) return -2;
-    if (dev_alloc(s, &s->posm_s, n) || dev_alloc(s, &s->colors, 3 * (n ? n : 1)) || dev_alloc(s, &s->info, 1)) return -2;
+    if (alloc_bodies(s, &s->buf[0], c) || alloc_bodies(s, &s->buf[1], c)) return -2;
+    if (dev_alloc(s, &s->posm_s, c) || dev_alloc(s, &s->colors, 3 * (c ? c : 1)) || dev_alloc(s, &s->info, 1)) return -2;
     void *stage = nullptr;
-    NBMI_HIP_CHECK(hipMalloc(&stage, (size_t)(n ? n : 1) * 7 * sizeof(double)));
+    NBMI_HIP_CHECK(hipMalloc(&stage, (size_t)(c ? c : 1) * 7 * sizeof(double)));
     s->allocs.push_back(stage);
     s->stage = stage;
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, sizeof(TreeInfo), s->stream));
-    NBMI_HIP_CHECK(hipMemsetAsync(s->colors, 0, (size_t)(n ? n : 1) * 3 * sizeof(float), s->stream));
+    NBMI_HIP_CHECK(hipMemsetAsync(s->colors, 0, (size_t)(c ? c : 1) * 3 * sizeof(float), s->stream));
     if (s->method == NBMI_METHOD_BARNES_HUT) {
-        s->node_capacity = node_rows_for(n);  // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N
-        if (dev_alloc(s, &s->key_hi, n) || dev_alloc(s, &s->key_lo, n) || dev_alloc(s, &s->hi_s, n) ||
-            dev_alloc(s, &s->lo_s, n) || dev_alloc(s, &s->p64_s, n) || dev_alloc(s, &s->idx, n) || dev_alloc(s, &s->perm, n) ||
-            dev_alloc(s, &s->delta, n) || dev_alloc(s, &s->cnt, n + 1) || dev_alloc(s, &s->Pex, n + 1) ||
-            dev_alloc(s, &s->S, n + 1) || dev_alloc(s, &s->tile_sum, (n + 1) / kScanTile + 2) || dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
-            dev_alloc(s, &s->node_level, s->node_capacity) || dev_alloc(s, &s->node_ref, s->node_capacity) || dev_alloc(s, &s->cell_r, s->node_capacity - n) ||
-            dev_alloc(s, &s->cell_lev, s->node_capacity - n))
+        // reference: max_nodes = min(8M, 4N) (simulation.py:477), + slack for tiny N; owner mode: + received trees
+        s->node_capacity = node_rows_for(c) + s->node_extra;
+        const int64_t own_rows = node_rows_for(c);
+        if (dev_alloc(s, &s->key_hi, c) || dev_alloc(s, &s->key_lo, c) || dev_alloc(s, &s->hi_s, c) ||
+            dev_alloc(s, &s->lo_s, c) || dev_alloc(s, &s->p64_s, c) || dev_alloc(s, &s->idx, c) || dev_alloc(s, &s->perm, c) ||
+            dev_alloc(s, &s->delta, c) || dev_alloc(s, &s->cnt, c + 1) || dev_alloc(s, &s->Pex, c + 1) ||
+            dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->tile_sum, (c + 1) / kScanTile + 2) ||
+            dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
+            dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
+            dev_alloc(s, &s->cell_r, own_rows - c) || dev_alloc(s, &s->cell_lev, own_rows - c))
             return -2;
-        s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)n, 0, 63);
+        s->own_node_rows = own_rows;
+        s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)c, 0, 63);
         char *t = nullptr;
         if (dev_alloc(s, &t, s->tmp_sort_bytes + 256)) return -2;
         s->tmp_sort = t;
@@ -1862,7 +2072,7 @@ int nbmi_get_masses_f64(nbmi_sim *s, double *out) {
     if (!out) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
     Bodies cur = s->buf[s->curbuf];
     // scatter to the caller's order through the 3-component un-permute (components 1, 2 unused)
-    k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(cur.m, cur.m, cur.m, cur.id, n, (double *)s->stage);
+    k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(cur.m, cur.m, cur.m, s->owner ? nullptr : cur.id, n, (double *)s->stage);
     NBMI_HIP_CHECK(hipGetLastError());
     std::vector<double> tmp((size_t)n * 3);
     NBMI_HIP_CHECK(hipMemcpyAsync(tmp.data(), s->stage, (size_t)n * 24, hipMemcpyDeviceToHost, s->stream));
@@ -1878,6 +2088,10 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
         return NBMI_ERR_ARG;
     }
     if (s->n == 0) return 0;
+    if (s->owner) {
+        nbmi::set_error("nbmi_step: this handle is in owner mode, use the nbmi_owner_* calls");
+        return NBMI_ERR_ARG;
+    }
     if (substeps > 1 && (s->shard_begin != 0 || s->shard_end != s->n)) {
         nbmi::set_error("nbmi_step: a sharded handle needs nbmi_import_ranks between steps (substeps must be 1)");
         return NBMI_ERR_ARG;
@@ -1921,7 +2135,7 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
 int nbmi_compute_colors(nbmi_sim *s, double max_speed) {
     if (int rc = check_handle(s)) return rc;
     if (s->n == 0) return 0;
-    k_colors<<<nblocks(s->n), kBlock, 0, s->stream>>>(s->buf[s->curbuf], s->n, max_speed, s->colors);
+    k_colors<<<nblocks(s->n), kBlock, 0, s->stream>>>(s->buf[s->curbuf], s->n, max_speed, s->owner, s->colors);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1937,8 +2151,9 @@ static int get3(nbmi_sim *s, const double *a, const double *b, const double *c, 
     const int64_t n = s->n;
     if (n == 0) return 0;
     Bodies cur = s->buf[s->curbuf];
-    if (f32) k_unperm3_f32<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, cur.id, n, (float *)s->stage);
-    else k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, cur.id, n, (double *)s->stage);
+    const int32_t *id = s->owner ? nullptr : cur.id;
+    if (f32) k_unperm3_f32<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, id, n, (float *)s->stage);
+    else k_unperm3_f64<<<nblocks(n), kBlock, 0, s->stream>>>(a, b, c, id, n, (double *)s->stage);
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipMemcpyAsync(out, s->stage, (size_t)n * 3 * (f32 ? sizeof(float) : sizeof(double)),
                                   hipMemcpyDeviceToHost, s->stream));
@@ -2175,72 +2390,231 @@ int nbmi_import_ranks(nbmi_sim *s, const void *dev_rows, int64_t begin, int64_t 
     return 0;
 }
 
-int nbmi_exchange_enable(nbmi_sim *s, int64_t n_total, int world, int64_t run_rows) {
+// =========================================================================================
+// Owner mode (multi-GPU stage 2).  See include/nbmi.h for the per-step protocol.
+// =========================================================================================
+namespace {
+int owner_check(nbmi_sim *s, const char *what) {
     if (int rc = check_handle(s)) return rc;
-    if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
-    if (s->world > 0) { nbmi::set_error("nbmi_exchange_enable: already enabled"); return NBMI_ERR_ARG; }
-    if (world < 1 || run_rows < s->n || n_total < s->n || n_total > (int64_t)world * run_rows || n_total > kMaxBodies) {
-        nbmi::set_error("nbmi_exchange_enable: bad sizes (n=%lld, n_total=%lld, world=%d, run_rows=%lld)",
-                        (long long)s->n, (long long)n_total, world, (long long)run_rows);
+    if (!s->owner) {
+        nbmi::set_error("%s: not an owner-mode handle (nbmi_create_owner)", what);
         return NBMI_ERR_ARG;
     }
-    const int64_t nt = n_total;
-    s->node_capacity = node_rows_for(nt);
-    // tree workspace for the whole system (the n-sized arrays of nbmi_create stay for the local sort)
-    if (dev_alloc(s, &s->t_hi, nt) || dev_alloc(s, &s->t_lo, nt) || dev_alloc(s, &s->t_posm, nt) ||
-        dev_alloc(s, &s->delta, nt) || dev_alloc(s, &s->cnt, nt + 1) || dev_alloc(s, &s->Pex, nt + 1) ||
-        dev_alloc(s, &s->S, nt + 1) || dev_alloc(s, &s->tile_sum, (nt + 1) / kScanTile + 2) ||
-        dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
-        dev_alloc(s, &s->node_level, s->node_capacity) ||
-        dev_alloc(s, &s->node_ref, s->node_capacity) ||
-        dev_alloc(s, &s->cell_r, s->node_capacity - nt) || dev_alloc(s, &s->cell_lev, s->node_capacity - nt))
-        return NBMI_ERR_HIP;
-    s->nt = nt;
-    s->world = world;
-    s->tree_valid = false;
-    return upload_walk_table(s);  // the node arrays were re-allocated for the whole system
+    return 0;
+}
+int enqueue_iscan(nbmi_sim *s, const int32_t *in, int64_t n, int32_t *out) {  // out has n + 1 entries
+    const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;
+    k_iscan_reduce<<<(int)ntiles, kBlock, 0, s->stream>>>(in, n, s->let_tiles);
+    k_iscan_tiles<<<1, kBlock, 0, s->stream>>>(s->let_tiles, ntiles);
+    k_iscan_apply<<<(int)ntiles, kBlock, 0, s->stream>>>(in, n, s->let_tiles, out);
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, const double *mass, const int32_t *ids,
+                            int64_t capacity, int64_t let_capacity, int world, int rank, double G, double softening,
+                            double damping, double theta, int device) {
+    nbmi::clear_error();
+    if (n < 0 || capacity < n || capacity < 1 || capacity > kMaxBodies || (n > 0 && (!pos || !vel || !mass || !ids)) ||
+        world < 1 || world > kMaxWorld || rank < 0 || rank >= world || let_capacity < 0 || !(softening >= 0.0) ||
+        !(theta >= 0.0)) {
+        nbmi::set_error("nbmi_create_owner: bad arguments (n=%lld, capacity=%lld, world=%d, rank=%d)", (long long)n,
+                        (long long)capacity, world, rank);
+        return nullptr;
+    }
+    const int count = nbmi_device_count();
+    if (count <= 0 || device < 0 || device >= count) {
+        nbmi::set_error("nbmi_create_owner: no HIP device %d (have %d)", device, count);
+        return nullptr;
+    }
+    nbmi_sim *s = new nbmi_sim();
+    s->n = n; s->cap = capacity; s->method = NBMI_METHOD_BARNES_HUT; s->device = device;
+    s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
+    s->owner = true; s->world = world; s->rank = rank;
+    s->let_capacity = let_capacity;
+    s->node_extra = let_capacity * (world - 1);
+    read_env_knobs(s);
+    int rc = create_impl(s, pos, vel, mass);
+    if (rc == 0) {
+        const int64_t c = s->cap, rows = s->node_capacity + 2;
+        if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) || dev_alloc(s, &s->let_dest_s, c) ||
+            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, kMaxWorld) || dev_alloc(s, &s->let_bbox, 6 * 256) ||
+            dev_alloc(s, &s->let_diff, rows) || dev_alloc(s, &s->let_scan, rows) || dev_alloc(s, &s->let_keep, rows) ||
+            dev_alloc(s, &s->let_tiles, rows / kScanTile + 4))
+            rc = -2;
+    }
+    if (rc == 0 && n > 0) {  // global ids instead of the row numbers k_split_state wrote
+        hipError_t e = hipMemcpyAsync(s->stage, ids, (size_t)n * 4, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) {
+            k_copy_ids<<<nblocks(n), kBlock, 0, s->stream>>>((const int32_t *)s->stage, s->buf[0].id, n);
+            e = hipStreamSynchronize(s->stream);
+        }
+        if (e != hipSuccess) { nbmi::set_error("nbmi_create_owner: id upload failed: %s", hipGetErrorString(e)); rc = -2; }
+    }
+    if (rc != 0) {
+        std::string keep = nbmi::get_error();
+        nbmi_destroy(s);
+        nbmi::set_error("%s", keep.c_str());
+        return nullptr;
+    }
+    return s;
 }
 
-int nbmi_exchange_maxabs(nbmi_sim *s, void *dev_maxabs) {
-    if (int rc = check_handle(s)) return rc;
-    if (s->world <= 0 || !dev_maxabs) { nbmi::set_error("nbmi_exchange_maxabs: exchange not enabled / null buffer"); return NBMI_ERR_ARG; }
-    if (int rc = enqueue_maxabs(s)) return rc;
+int64_t nbmi_owner_count(nbmi_sim *s) { return s ? s->n : -1; }
+
+int nbmi_owner_get_ids(nbmi_sim *s, int32_t *out) {
+    if (int rc = owner_check(s, "nbmi_owner_get_ids")) return rc;
+    if (s->n == 0) return 0;
+    if (!out) { nbmi::set_error("null output"); return NBMI_ERR_ARG; }
+    NBMI_HIP_CHECK(hipMemcpyAsync(out, s->buf[s->curbuf].id, (size_t)s->n * 4, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_owner_maxabs(nbmi_sim *s, void *dev_maxabs) {
+    if (int rc = owner_check(s, "nbmi_owner_maxabs")) return rc;
+    if (!dev_maxabs) { nbmi::set_error("nbmi_owner_maxabs: null buffer"); return NBMI_ERR_ARG; }
+    if (int rc = enqueue_maxabs(s)) return rc;  // also clears the per-step tree header
     // a non-negative double and its bit pattern order the same way: the word IS the double
     NBMI_HIP_CHECK(hipMemcpyAsync(dev_maxabs, &s->info->maxabs_bits, 8, hipMemcpyDeviceToDevice, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     return 0;
 }
 
-int nbmi_exchange_export(nbmi_sim *s, const void *dev_maxabs, void *dev_run, int64_t run_rows) {
-    if (int rc = check_handle(s)) return rc;
-    if (s->world <= 0 || !dev_maxabs || !dev_run || run_rows < s->n) {
-        nbmi::set_error("nbmi_exchange_export: exchange not enabled / bad buffers");
-        return NBMI_ERR_ARG;
-    }
-    NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, s->stream));
-    if (s->n > 0)
-        if (int rc = enqueue_local_sort(s, -1)) return rc;
-    k_pack_run<<<nblocks(run_rows), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->posm_s, s->n, run_rows, (RunRec *)dev_run);
-    NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
-    return 0;
-}
-
-int nbmi_exchange_step(nbmi_sim *s, const void *dev_runs, int world, int64_t run_rows, double dt) {
-    if (int rc = check_handle(s)) return rc;
-    if (s->world <= 0 || world != s->world || !dev_runs || (int64_t)world * run_rows < s->nt) {
-        nbmi::set_error("nbmi_exchange_step: exchange not enabled / sizes differ from nbmi_exchange_enable");
+int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, int nsamples) {
+    if (int rc = owner_check(s, "nbmi_owner_sample")) return rc;
+    if (!dev_maxabs || !dev_samples || nsamples < 1 || (int64_t)nsamples * s->world > kSampleCap) {
+        nbmi::set_error("nbmi_owner_sample: bad arguments (at most %d samples over all ranks)", kSampleCap);
         return NBMI_ERR_ARG;
     }
     hipStream_t st = s->stream;
-    const int64_t rows = (int64_t)world * run_rows;
-    int steps = 1;
-    while ((1ll << steps) <= run_rows) steps++;  // iterations that empty a search range of run_rows
-    k_merge_ranks<<<nblocks(rows), kBlock, 0, st>>>((const RunRec *)dev_runs, world, (int)run_rows, s->nt, steps, s->t_hi,
-                                                    s->t_lo, s->t_posm, s->info);
-    if (int rc = enqueue_global_tree(s)) return rc;
-    if (s->n > 0)
-        if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
+    Bodies cur = s->buf[s->curbuf];
+    if (s->n > 0) k_keys<<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
+    k_key_samples<<<(nsamples + kBlock - 1) / kBlock, kBlock, 0, st>>>(s->key_hi, s->n, nsamples, (uint64_t *)dev_samples);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_samples, void *dev_send_rows,
+                         int64_t *counts /* world, host */) {
+    if (int rc = owner_check(s, "nbmi_owner_partition")) return rc;
+    if (!dev_all_samples || !counts || total_samples < 1 || total_samples > kSampleCap || (s->n > 0 && !dev_send_rows)) {
+        nbmi::set_error("nbmi_owner_partition: bad arguments");
+        return NBMI_ERR_ARG;
+    }
+    hipStream_t st = s->stream;
+    const int64_t n = s->n;
+    k_splitters<<<1, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, s->world, s->let_split);
+    if (n > 0) {
+        k_dest<<<nblocks(n), kBlock, 0, st>>>(s->key_hi, n, s->let_split, s->world, s->let_dest, s->idx);
+        // stable sort by destination: rows of one destination leave in their current (key) order
+        NBMI_HIP_CHECK(nbmi::sort_pairs_u32_u32(s->tmp_sort, s->tmp_sort_bytes, s->let_dest, s->let_dest_s, s->idx, s->let_order,
+                                                (size_t)n, 0, 8, st));
+        k_pack_rows_perm<<<nblocks(n), kBlock, 0, st>>>(s->buf[s->curbuf], s->let_order, n, (double *)dev_send_rows);
+    }
+    k_dest_counts<<<1, kMaxWorld, 0, st>>>(s->let_dest_s, n, s->world, s->let_counts);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)s->world * 8, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_bbox6) {
+    if (int rc = owner_check(s, "nbmi_owner_adopt")) return rc;
+    if (n_new < 0 || n_new > s->cap) {
+        nbmi::set_error("nbmi_owner_adopt: %lld bodies do not fit the capacity of %lld (raise the head room)", (long long)n_new,
+                        (long long)s->cap);
+        return NBMI_ERR_CAPACITY;
+    }
+    if ((n_new > 0 && !dev_recv_rows) || !dev_maxabs || !dev_bbox6) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
+    hipStream_t st = s->stream;
+    s->n = n_new; s->nt = n_new; s->shard_begin = 0; s->shard_end = n_new;
+    Bodies cur = s->buf[s->curbuf];
+    if (n_new > 0) k_unpack_rows<<<nblocks(n_new), kBlock, 0, st>>>(cur, 0, n_new, (const double *)dev_recv_rows);
+    // the tree header of this step: cleared, then the GLOBAL extent (every rank builds inside the same root cube)
+    NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
+    if (n_new > 0) {
+        if (int rc = enqueue_local_sort(s, -1)) return rc;
+        if (int rc = enqueue_global_tree(s)) return rc;
+        int gb = nblocks(n_new);
+        if (gb > 256) gb = 256;
+        k_bbox_blocks<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n_new, s->let_bbox);
+        k_bbox_final<<<1, 64, 0, st>>>(s->let_bbox, gb, (double *)dev_bbox6);
+    } else {
+        const double empty[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        NBMI_HIP_CHECK(hipMemcpyAsync(dev_bbox6, empty, sizeof(empty), hipMemcpyHostToDevice, st));
+    }
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    s->tree_valid = n_new > 0;
+    return 0;
+}
+
+int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int64_t *count) {
+    if (int rc = owner_check(s, "nbmi_owner_export_let")) return rc;
+    if (!dev_boxes || !dev_let || !count) { nbmi::set_error("nbmi_owner_export_let: null buffer"); return NBMI_ERR_ARG; }
+    *count = 0;
+    if (s->n == 0) return 0;
+    hipStream_t st = s->stream;
+    TreeInfo h;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (h.error) return check_device_error(s);
+    const int64_t nn = h.num_nodes;
+    NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)(nn + 1) * 4, st));
+    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->world, s->rank, s->theta,
+                                              s->softening * s->softening, s->let_diff);
+    if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan)) return rc;
+    k_let_keep<<<nblocks(nn), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, s->let_keep);
+    if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan)) return rc;
+    Node *out_nodes = (Node *)dev_let;
+    Node64 *out_n64 = (Node64 *)((char *)dev_let + (size_t)s->let_capacity * kNodeBytes);
+    k_let_compact<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, s->let_capacity, out_nodes,
+                                                 out_n64);
+    NBMI_HIP_CHECK(hipGetLastError());
+    int32_t total = 0;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&total, s->let_scan + nn, 4, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (total > s->let_capacity) {
+        nbmi::set_error("nbmi_owner_export_let: the locally essential tree has %d nodes, more than the %lld rows reserved",
+                        total, (long long)s->let_capacity);
+        return NBMI_ERR_CAPACITY;
+    }
+    *count = total;
+    return 0;
+}
+
+int nbmi_owner_step(nbmi_sim *s, const void *dev_lets, const int64_t *counts, double dt) {
+    if (int rc = owner_check(s, "nbmi_owner_step")) return rc;
+    if (!counts || (s->world > 1 && !dev_lets)) { nbmi::set_error("nbmi_owner_step: null buffer"); return NBMI_ERR_ARG; }
+    if (s->n == 0) return 0;
+    hipStream_t st = s->stream;
+    TreeInfo h;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (h.error) return check_device_error(s);
+    int64_t total = h.num_nodes;
+    const size_t stride = (size_t)s->let_capacity * (kNodeBytes + sizeof(Node64));
+    for (int j = 0; j < s->world; j++) {
+        if (j == s->rank || counts[j] <= 0) continue;
+        if (counts[j] > s->let_capacity || total + counts[j] + 1 > s->node_capacity) {
+            nbmi::set_error("nbmi_owner_step: received trees do not fit (%lld + %lld of %lld rows)", (long long)total,
+                            (long long)counts[j], (long long)s->node_capacity);
+            return NBMI_ERR_CAPACITY;
+        }
+        const char *base = (const char *)dev_lets + stride * j;
+        k_let_append<<<nblocks(counts[j]), kBlock, 0, st>>>((const Node *)base,
+                                                            (const Node64 *)(base + (size_t)s->let_capacity * kNodeBytes),
+                                                            counts[j], total, s->nodes, s->nodes64);
+        total += counts[j];
+    }
+    k_let_finish<<<1, 1, 0, st>>>(s->nodes, total, s->info);
+    NBMI_HIP_CHECK(hipGetLastError());
+    if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
     s->curbuf ^= 1;
     s->tree_valid = false;
     return 0;
@@ -2265,6 +2639,7 @@ struct EmitPoints {
 int nbmi_visible_points(nbmi_sim *s, const double *cam12, double tan_h, double tan_v, double far_dist, float *out_pos,
                         float *out_col, int64_t capacity, int64_t *count) {
     if (int rc = check_handle(s)) return rc;
+    if (s->owner) { nbmi::set_error("nbmi_visible_points: not available on an owner-mode handle"); return NBMI_ERR_ARG; }
     if (!cam12 || !count || capacity < 0 || (capacity > 0 && (!out_pos || !out_col))) {
         nbmi::set_error("nbmi_visible_points: null argument");
         return NBMI_ERR_ARG;

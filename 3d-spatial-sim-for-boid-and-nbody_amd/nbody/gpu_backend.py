@@ -286,21 +286,69 @@ class HIPBarnesHutSimulation(_HIPSimulation):
         _nat.check(self._lib.nbmi_get_order(self._h, _nat.ptr(out)), "nbmi_get_order")
         return out
 
-    # multi-GPU hooks (device pointers; see nbody/sharded.py)
-    def exchange_enable(self, n_total, world, run_rows):
-        _nat.check(self._lib.nbmi_exchange_enable(self._h, int(n_total), int(world), int(run_rows)),
-                   "nbmi_exchange_enable")
 
-    def exchange_maxabs(self, dev_ptr):
-        _nat.check(self._lib.nbmi_exchange_maxabs(self._h, int(dev_ptr)), "nbmi_exchange_maxabs")
+class HIPOwnerSimulation(HIPBarnesHutSimulation):
+    """Owner-mode handle of the multi-GPU stage 2 (include/nbmi.h, nbmi_create_owner): the bodies of one
+    octant-key range, their own octree inside the global root cube, plus received locally essential trees.
+    Driven by nbody/sharded.py::LetBarnesHut; buffers are device pointers."""
 
-    def exchange_export(self, dev_maxabs, dev_run, run_rows):
-        _nat.check(self._lib.nbmi_exchange_export(self._h, int(dev_maxabs), int(dev_run), int(run_rows)),
-                   "nbmi_exchange_export")
+    def __init__(self, positions, velocities, masses, global_ids, capacity, let_capacity, world, rank, G, softening,
+                 damping, theta=0.5, device=None):
+        lib = _nat.load()
+        pos = _as_f64(positions, (3,))
+        vel = _as_f64(velocities, (3,))
+        m = _as_f64(masses, ())
+        ids = np.ascontiguousarray(global_ids, dtype=np.int32)
+        if not (len(pos) == len(vel) == len(m) == len(ids)):
+            raise ValueError("positions, velocities, masses and ids must have the same length")
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, _nat.device_count())
+        self.G, self.softening, self.damping, self.theta = float(G), float(softening), float(damping), float(theta)
+        self.device = int(device)
+        self.world, self.rank = int(world), int(rank)
+        self.capacity, self.let_capacity = int(capacity), int(let_capacity)
+        self._lib = lib
+        self._h = lib.nbmi_create_owner(len(pos), _nat.ptr(pos), _nat.ptr(vel), _nat.ptr(m), _nat.ptr(ids), self.capacity,
+                                        self.let_capacity, self.world, self.rank, self.G, self.softening, self.damping,
+                                        self.theta, self.device)
+        if not self._h:
+            raise RuntimeError(f"nbmi_create_owner failed: {_nat.last_error()}")
+        print(f"[HIP] rank {rank}/{world}: owner of {len(pos):,} bodies (capacity {capacity:,}) on device {self.device}")
 
-    def exchange_step(self, dev_runs, world, run_rows, dt):
-        _nat.check(self._lib.nbmi_exchange_step(self._h, int(dev_runs), int(world), int(run_rows), float(dt)),
-                   "nbmi_exchange_step")
+    @property
+    def n(self):
+        return int(self._lib.nbmi_owner_count(self._h)) if self._h else 0
+
+    def ids(self):
+        out = np.empty(self.n, dtype=np.int32)
+        _nat.check(self._lib.nbmi_owner_get_ids(self._h, _nat.ptr(out)), "nbmi_owner_get_ids")
+        return out
+
+    def owner_maxabs(self, dev_maxabs):
+        _nat.check(self._lib.nbmi_owner_maxabs(self._h, int(dev_maxabs)), "nbmi_owner_maxabs")
+
+    def owner_sample(self, dev_maxabs, dev_samples, nsamples):
+        _nat.check(self._lib.nbmi_owner_sample(self._h, int(dev_maxabs), int(dev_samples), int(nsamples)), "nbmi_owner_sample")
+
+    def owner_partition(self, dev_all_samples, total, dev_send_rows):
+        counts = np.zeros(self.world, dtype=np.int64)
+        _nat.check(self._lib.nbmi_owner_partition(self._h, int(dev_all_samples), int(total), int(dev_send_rows),
+                                                  _nat.ptr(counts)), "nbmi_owner_partition")
+        return counts
+
+    def owner_adopt(self, dev_recv_rows, n_new, dev_maxabs, dev_bbox):
+        _nat.check(self._lib.nbmi_owner_adopt(self._h, int(dev_recv_rows), int(n_new), int(dev_maxabs), int(dev_bbox)),
+                   "nbmi_owner_adopt")
+
+    def owner_export_let(self, dev_boxes, dev_let):
+        cnt = C.c_int64(0)
+        _nat.check(self._lib.nbmi_owner_export_let(self._h, int(dev_boxes), int(dev_let), C.addressof(cnt)),
+                   "nbmi_owner_export_let")
+        return int(cnt.value)
+
+    def owner_step(self, dev_lets, counts, dt):
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        _nat.check(self._lib.nbmi_owner_step(self._h, int(dev_lets), _nat.ptr(counts), float(dt)), "nbmi_owner_step")
 
 
 class HIPDirectSimulation(_HIPSimulation):

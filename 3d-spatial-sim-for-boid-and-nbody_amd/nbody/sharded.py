@@ -1,24 +1,26 @@
 """Multi-GPU Barnes-Hut: one process per GPU, bodies sharded by octant-key range.
 
-The reference is single-device; this is new design, in two forms, both bit-identical
-to the 1-GPU result (the force on a body depends only on the global tree and on its own state):
+The reference is single-device; this is new design, in two forms:
 
-* **row exchange** (``ShardedBarnesHut``, stage 1, the default of ``create_sharded_simulation``):
-  every rank holds all N bodies, sorts and builds over all of them, integrates one contiguous
-  range of sorted ranks (always a compact region, whatever the bodies did), and all-gathers the
-  updated rows {x,y,z,vx,vy,vz,m,id} (64 B per body).
-* **run exchange** (``RunExchangeBarnesHut``, experimental): a rank OWNS a fixed set of bodies
-  (initially one contiguous range of the key order) and keeps their float64 state to itself.  Per
-  step: all-reduce MAX of one double (the root cube), local keys + local sort, all-gather of the
-  key-sorted runs (32 B per body: two key words + fp32 x,y,z,G m), merge of the ``world`` sorted
-  runs, octree over the whole system, walk + integrate the owned bodies.  Half the bytes on the
-  wire and no whole-system sort, but measured it only pays with body
-  MIGRATION: a body that leaves its owner's region keeps its owner, lands in a wave with other
-  emigrants from all over the system, and that one wave then walks ~64 bodies' worth of distinct
-  paths serially (walk 1.7 -> 5-7 ms after a single step at 4 x 1 M).  It is the stepping stone to
-  the locally-essential-tree exchange, not the production path.
+* **row exchange** (``ShardedBarnesHut``, stage 1, ``mode="rows"``): every rank holds all N bodies, sorts
+  and builds over all of them, integrates one contiguous range of sorted ranks, and all-gathers the
+  updated rows {x,y,z,vx,vy,vz,m,id} (64 B per body).  Bit-identical to the 1-GPU result for any world
+  size (the force on a body depends only on the global tree and on its own state); per-rank sort, build
+  and memory grow with the whole system - it is the exact reference mode, not the scaling one.
+* **locally essential trees** (``LetBarnesHut``, stage 2, ``mode="let"`` - the form BASELINE's north_star
+  names): a rank OWNS the bodies of one key range.  Per step: all-reduce MAX of one double (the root cube
+  of the whole system), keys, all-gather of a few hundred key samples -> splitters at equal quantiles,
+  all-to-all-v of the rows that crossed a splitter (body migration: a rank's bodies always form one compact
+  key range, so its waves stay compact), local sort + octree of the owned bodies inside the global cube,
+  all-gather of the ranks' bounding boxes, pruning of the own tree against the others' boxes (the
+  reference's opening test at the box's nearest point, conservative by 1e-9), all-gather of the pruned
+  trees (56 B per node: the 24-byte walk record and its float64 twin), walk over own + received trees.
+  Per-rank sort / build / state no longer grow with the world size; only the received trees do.  Cells
+  that straddle rank boundaries appear once per rank (partial cells), so positions agree with the 1-GPU
+  run to a stated tolerance instead of bit for bit.
 
-Collectives are ``torch.distributed`` calls on device buffers (backend "nccl" = RCCL over xGMI).
+Collectives are ``torch.distributed`` calls on device buffers (backend "nccl" = RCCL over xGMI), behind a
+small comm interface so that tests can play the ranks with threads on one GPU.
 
 ``ShardedBarnesHut`` is written against a small shard-engine interface so the collective logic
 can be exercised on CPU (gloo) with a stand-in engine:
@@ -136,94 +138,163 @@ class ShardedBarnesHut:
 def create_sharded_simulation(positions, velocities, masses, G, softening, damping, theta=0.5, mode="rows",
                               method="barnes_hut"):
     """Build the multi-GPU stepper from the torch.distributed environment (RANK/LOCAL_RANK/
-    WORLD_SIZE).  Every rank passes the same full arrays.  mode: "rows" (stage 1, replicated state)
-    or "runs" (experimental run exchange with fixed ownership); method "direct" shards the all-pairs
-    kernel by body index through the same row exchange."""
+    WORLD_SIZE).  Every rank passes the same full arrays.  mode: "rows" (stage 1, replicated state and
+    tree, bit-exact) or "let" (stage 2, owned key ranges + locally essential trees); method "direct"
+    shards the all-pairs kernel by body index through the row exchange."""
     import os
+    import torch
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    import torch
     local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
     if mode == "rows" or method == "direct":
         eng = HipShardEngine(positions, velocities, masses, G, softening, damping, theta, local, method=method)
         # (a process group of one rank still runs the collective: used to smoke-test RCCL on a 1-GPU box)
         return ShardedBarnesHut(eng, len(positions), rank, world, dist if dist.is_initialized() else None)
-    if mode != "runs":
+    if mode != "let":
         raise ValueError(f"unknown sharding mode {mode!r}")
-    eng = HipRunEngine(positions, velocities, masses, G, softening, damping, theta, local, rank, world)
-    return RunExchangeBarnesHut(eng, rank, world, DistComm(dist) if world > 1 else None)
+    eng = HipLetEngine(positions, velocities, masses, G, softening, damping, theta, local, rank, world)
+    return LetBarnesHut(eng, rank, world, DistComm(dist, eng.device) if dist.is_initialized() else None)
 
 
-class HipRunEngine:
-    """Owner engine of the run exchange: this rank's bodies in one libnbmi handle."""
+def let_capacities(n_total, world):
+    """(body capacity, rows of one locally essential tree) of a rank: 25 % head room over the equal share
+    (the splitters re-balance every step, so the share only drifts by sampling noise) and, for the tree a
+    rank sends to the others, a generous fraction of its own ~1.5 n nodes (measured: 3-12 %)."""
+    share = (n_total + world - 1) // world
+    cap = int(share * 1.25) + 4096
+    let = 0 if world == 1 else int(0.6 * share) + 65536
+    return cap, let
+
+
+class HipLetEngine:
+    """This rank's bodies in one owner-mode libnbmi handle; exchange buffers are torch CUDA tensors."""
+
+    SAMPLES = 256        # key samples per rank for the splitters
+    LET_ROW_BYTES = 56   # 24-byte walk record + 32-byte float64 twin
 
     def __init__(self, positions, velocities, masses, G, softening, damping, theta, device, rank, world):
         import torch
-        from .gpu_backend import HIPBarnesHutSimulation
+        from .gpu_backend import HIPBarnesHutSimulation, HIPOwnerSimulation
         self.torch = torch
         self.device = torch.device("cuda", device)
-        self.n_total = len(positions)
-        self.per, begin, end = shard_bounds(self.n_total, world, rank)
+        self.rank, self.world = rank, world
+        self.n_total = n = len(positions)
+        per, begin, end = shard_bounds(n, world, rank)
         if world == 1:
-            self.ids = np.arange(self.n_total, dtype=np.int64)
+            ids = np.arange(n, dtype=np.int32)
         else:
-            # initial owners: contiguous ranges of the key order (compact wave groups)
+            # initial owners: contiguous ranges of the key order (the first step re-balances anyway)
             full = HIPBarnesHutSimulation(positions, velocities, masses, G, softening, damping, theta, device=device)
             full.build_tree()
-            self.ids = full.key_order()[begin:end].astype(np.int64)
+            ids = full.key_order()[begin:end].astype(np.int32)
             full.close()
-        self.sim = HIPBarnesHutSimulation(np.asarray(positions)[self.ids], np.asarray(velocities)[self.ids],
-                                          np.asarray(masses)[self.ids], G, softening, damping, theta, device=device)
-        self.n = self.sim.n
-        self.world = world
-        self.sim.exchange_enable(self.n_total, world, self.per)
+        cap, let = let_capacities(n, world)
+        self.cap, self.let_rows = cap, let
+        self.SAMPLES = min(self.SAMPLES, 4096 // world)  # the library sorts world x SAMPLES keys in one workgroup
+        self.sim = HIPOwnerSimulation(np.asarray(positions)[ids], np.asarray(velocities)[ids], np.asarray(masses)[ids], ids,
+                                      cap, let, world, rank, G, softening, damping, theta, device=device)
+        f64, i64 = torch.float64, torch.int64
+        z = lambda *shape, dtype=f64: torch.zeros(shape, dtype=dtype, device=self.device)  # noqa: E731
+        self.maxabs = z(1)
+        self.samples = z(self.SAMPLES, dtype=i64)
+        self.all_samples = z(world * self.SAMPLES, dtype=i64)
+        self.send_rows = z(cap, ROW)
+        self.recv_rows = z(cap, ROW)
+        self.bbox = z(6)
+        self.boxes = z(world * 6)
+        let_bytes = let * 56  # 24-byte walk record + 32-byte float64 twin
+        self.let_mine = torch.zeros(max(let_bytes, 8), dtype=torch.uint8, device=self.device)
+        self.let_all = torch.zeros(max(let_bytes, 8) * world, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)  # the fills ran on torch's stream, the library has its own
+        self.wire_bytes = 0  # bytes this rank sent in the last step (rows + tree + small collectives)
+        self.migrated = 0    # bodies this rank handed to other ranks in the last step
+        self.let_counts = np.zeros(world, dtype=np.int64)
 
-    def new_maxabs(self):
-        return self.torch.zeros(1, dtype=self.torch.float64, device=self.device)
+    # ---- the six phases of a step (LetBarnesHut puts the collectives between them) ------------------
+    def op_maxabs(self):
+        self.sim.owner_maxabs(self.maxabs.data_ptr())
 
-    def new_run(self, rows):
-        return self.torch.zeros((rows, 4), dtype=self.torch.int64, device=self.device)  # 32-byte records
+    def op_sample(self):
+        self.sim.owner_sample(self.maxabs.data_ptr(), self.samples.data_ptr(), self.SAMPLES)
 
-    def local_maxabs(self, out):
-        self.sim.exchange_maxabs(out.data_ptr())  # synchronises the library stream
+    def op_partition(self, all_samples):
+        return self.sim.owner_partition(all_samples.data_ptr(), all_samples.numel(), self.send_rows.data_ptr())
 
-    def export_run(self, maxabs, out):
-        self.torch.cuda.current_stream(self.device).synchronize()  # all-reduce finished
-        self.sim.exchange_export(maxabs.data_ptr(), out.data_ptr(), out.shape[0])
+    def op_adopt(self, rows, n_new):
+        self.sim.owner_adopt(rows.data_ptr(), n_new, self.maxabs.data_ptr(), self.bbox.data_ptr())
 
-    def step_runs(self, full, dt):
-        self.torch.cuda.current_stream(self.device).synchronize()  # all-gather finished
-        self.sim.exchange_step(full.data_ptr(), self.world, full.shape[0] // self.world, dt)
+    def op_export_let(self):
+        return self.sim.owner_export_let(self.boxes.data_ptr(), self.let_mine.data_ptr())
+
+    def op_step(self, counts, dt):
+        self.sim.owner_step(self.let_all.data_ptr(), counts, dt)
+
+    def wait(self):
+        """A collective issued on torch's stream has finished (the library works on its own stream)."""
+        self.torch.cuda.current_stream(self.device).synchronize()
 
     def owned_state(self):
         """(global ids, positions f64, velocities f64) of the owned bodies."""
-        return self.ids, self.sim.get_positions_f64(), self.sim.get_velocities()
+        return self.sim.ids().astype(np.int64), self.sim.get_positions_f64(), self.sim.get_velocities()
 
 
-class RunExchangeBarnesHut:
-    """step() over `world` ranks with fixed body ownership; see the module docstring.
-    `comm` needs all_reduce_max(tensor) and all_gather(full, mine) (default: torch.distributed)."""
+class LetBarnesHut:
+    """step() over `world` ranks in owner mode; see the module docstring.  The engine owns the buffers
+    (maxabs, samples / all_samples, send_rows / recv_rows, bbox / boxes, let_mine / let_all: torch tensors)
+    and the six phases op_*; `comm` provides all_reduce_max(t), all_gather(full, mine),
+    all_to_all_counts(np int64[world]) -> np int64[world], all_gather_counts(int) -> np int64[world] and
+    all_to_all_rows(recv, send, recv_counts, send_counts) (default: torch.distributed, DistComm)."""
 
     def __init__(self, engine, rank, world, comm=None):
         self.engine, self.rank, self.world = engine, rank, world
         self.comm = comm
         self.n = engine.n_total
-        self.per = engine.per
-        self.maxabs = engine.new_maxabs()
-        self.mine = engine.new_run(self.per)
-        self.full = engine.new_run(self.per * world) if world > 1 else self.mine
+        if world > 1 and comm is None:
+            raise ValueError("LetBarnesHut over more than one rank needs a communicator")
 
     def step(self, dt, substeps=1):
-        e = self.engine
+        e, W = self.engine, self.world
         for _ in range(substeps):
-            e.local_maxabs(self.maxabs)
-            if self.world > 1:
-                self.comm.all_reduce_max(self.maxabs)
-            e.export_run(self.maxabs, self.mine)
-            if self.world > 1:
-                self.comm.all_gather(self.full, self.mine)
-            e.step_runs(self.full, dt)
+            wire = 0
+            e.op_maxabs()
+            if W > 1:
+                self.comm.all_reduce_max(e.maxabs)
+                e.wait()
+                wire += 8
+            e.op_sample()
+            allsamp = e.samples
+            if W > 1:
+                self.comm.all_gather(e.all_samples, e.samples)
+                e.wait()
+                wire += 8 * e.SAMPLES
+                allsamp = e.all_samples
+            send_counts = e.op_partition(allsamp)
+            if W > 1:
+                recv_counts = self.comm.all_to_all_counts(send_counts)
+                n_new = int(recv_counts.sum())
+                if n_new > e.cap:
+                    raise RuntimeError(f"rank {self.rank}: {n_new} bodies after migration exceed the capacity {e.cap}")
+                self.comm.all_to_all_rows(e.recv_rows, e.send_rows, recv_counts, send_counts)
+                e.wait()
+                wire += int(send_counts.sum() - send_counts[self.rank]) * ROW * 8
+                rows = e.recv_rows
+            else:
+                n_new, rows = int(send_counts[0]), e.send_rows
+            e.op_adopt(rows, n_new)
+            counts = np.zeros(W, dtype=np.int64)
+            if W > 1:
+                self.comm.all_gather(e.boxes, e.bbox)
+                e.wait()
+                mine = e.op_export_let()
+                counts = self.comm.all_gather_counts(mine)
+                self.comm.all_gather(e.let_all, e.let_mine)
+                e.wait()
+                wire += 48 + mine * e.LET_ROW_BYTES
+            e.op_step(counts, dt)
+            e.let_counts = counts
+            e.wire_bytes = wire
+            e.migrated = int(send_counts.sum() - send_counts[self.rank])
 
     def gather_state(self):
         """Full (positions, velocities) float64 in the caller's original order, on every rank."""
@@ -233,33 +304,77 @@ class RunExchangeBarnesHut:
             out_p[ids], out_v[ids] = pos, vel
             return out_p, out_v
         import torch
-        mine = torch.full((self.per, 7), -1.0, dtype=torch.float64)
+        cap = self.engine.cap
+        mine = torch.full((cap, 7), -1.0, dtype=torch.float64)
         mine[: len(ids), 0] = torch.from_numpy(ids.astype(np.float64))
         mine[: len(ids), 1:4] = torch.from_numpy(pos)
         mine[: len(ids), 4:7] = torch.from_numpy(vel)
-        dev = self.full.device
+        dev = self.engine.maxabs.device
         mine = mine.to(dev)
-        full = torch.empty((self.per * self.world, 7), dtype=torch.float64, device=dev)
+        full = torch.empty((cap * self.world, 7), dtype=torch.float64, device=dev)
         self.comm.all_gather(full, mine)
+        self.engine.wait()
         rows = full.cpu().numpy()
         rows = rows[rows[:, 0] >= 0]
         out_p, out_v = np.empty((self.n, 3)), np.empty((self.n, 3))
         gid = rows[:, 0].astype(np.int64)
+        assert len(np.unique(gid)) == self.n, "every body must have exactly one owner"
         out_p[gid], out_v[gid] = rows[:, 1:4], rows[:, 4:7]
         return out_p, out_v
 
 
 class DistComm:
-    """The two collectives of the run exchange on torch.distributed."""
+    """The collectives of the owner mode on torch.distributed.  Backend "nccl" (= RCCL over xGMI) works on the
+    device tensors directly; any other backend (gloo: CPU tests, 1-GPU rehearsals) goes through host copies."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, device=None):
         self.dist = dist
+        self.device = device
+        self.direct = dist.get_backend() == "nccl"
+
+    def _run(self, fn, outs, ins):
+        """fn(*outs, *ins) on tensors the backend can take; results copied back into `outs`."""
+        if self.direct or all(t.device.type == "cpu" for t in outs + ins):
+            return fn(*outs, *ins)
+        h_out = [t.cpu() for t in outs]
+        fn(*h_out, *[t.cpu() for t in ins])
+        for t, h in zip(outs, h_out):
+            t.copy_(h)
 
     def all_reduce_max(self, t):
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self._run(lambda x: self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX), [t], [])
 
     def all_gather(self, full, mine):
-        self.dist.all_gather_into_tensor(full, mine)
+        self._run(lambda f, m: self.dist.all_gather_into_tensor(f, m), [full], [mine])
+
+    def _small(self, values):
+        import torch
+        dev = self.device if self.direct else "cpu"
+        return torch.tensor(np.asarray(values, dtype=np.int64), dtype=torch.int64, device=dev)
+
+    def all_to_all_counts(self, send_counts):
+        import torch
+        s = self._small(send_counts)
+        r = torch.empty_like(s)
+        self.dist.all_to_all_single(r, s)
+        return r.cpu().numpy()
+
+    def all_gather_counts(self, mine):
+        import torch
+        s = self._small([mine])
+        r = torch.empty(self.dist.get_world_size(), dtype=torch.int64, device=s.device)
+        self.dist.all_gather_into_tensor(r, s)
+        return r.cpu().numpy()
+
+    def all_to_all_rows(self, recv, send, recv_counts, send_counts):
+        n_in, n_out = int(recv_counts.sum()), int(send_counts.sum())
+        rs, ss = [int(c) for c in recv_counts], [int(c) for c in send_counts]
+        if self.direct or recv.device.type == "cpu":
+            self.dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=rs, input_split_sizes=ss)
+            return
+        h = recv[:n_in].cpu()
+        self.dist.all_to_all_single(h, send[:n_out].cpu(), output_split_sizes=rs, input_split_sizes=ss)
+        recv[:n_in].copy_(h)
 
 
 def unpack_rows(rows: np.ndarray):

@@ -8,9 +8,11 @@ A "step" is one full timestep of the workload (bounds -> keys -> sort -> octree 
 fused kick-drift) with the bodies already resident in HBM.  Default workload = BASELINE config 2
 (galaxy, 1 M bodies per GPU, theta 0.5, dt 0.05, G 0.07, eps 1.5, R 800; synthetic IC from the
 reference's generator restated in tools/presets.py, seed 42).  With N > 1 the work per GPU is
-fixed (weak scaling): N x 1 M bodies, every rank builds the full octree and walks its own
-key-range, one RCCL all-gather of the updated rows per step (nbody/sharded.py;
-NBMI_SHARD_MODE=runs selects the experimental fixed-ownership run exchange).
+fixed (weak scaling): N x 1 M bodies, every rank owns one octant-key range (re-balanced every step, bodies
+migrate by an all-to-all), builds the octree of its own bodies and receives the other ranks' locally
+essential trees by an RCCL all-gather (nbody/sharded.py "let"; NBMI_SHARD_MODE=rows selects the
+replicated-tree exchange that is bit-identical to one GPU).  `python bench.py --gpus N` typed plainly
+starts its own N ranks.
 
 Rank 0 prints ONE JSON line.  At N = 1 it also carries
   roofline     - dominant kernel (k_walk): algorithmic bytes per launch / its mean duration,
@@ -296,7 +298,9 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
     p, v, m = make_ic(dist_name, n_total, R, G)
 
     from nbody import gpu_backend as gb
-    shard_mode = os.environ.get("NBMI_SHARD_MODE", "rows")
+    # N > 1, Barnes-Hut: "let" = owned key ranges + exchanged locally essential trees (BASELINE north_star's form,
+    # per-rank cost does not grow with N); "rows" = replicated tree, bit-identical to one GPU (the exact mode)
+    shard_mode = os.environ.get("NBMI_SHARD_MODE", "let")
     with contextlib.redirect_stdout(sys.stderr):  # backend banners must not pollute the one JSON line
         if use_dist:
             import torch.distributed as dist
@@ -304,6 +308,7 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
             sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode, method=method)
             sim = sharded.engine.sim
             step = lambda k: sharded.step(dt, k)  # noqa: E731
+            del p, v, m  # every rank generated the whole system to pick its share; only the share stays
         else:
             sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=dev) if method == "barnes_hut"
                    else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=dev))
@@ -332,7 +337,6 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         par = {"rows": f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows",
                "let": f"x{world}: key-range owners, body migration (all-to-all), per-rank octree, all-gather of "
                       "locally essential cells",
-               "runs": f"x{world}: fixed owners, all-gather of sorted 32-B runs, merged whole-system octree"
                }.get(shard_mode, shard_mode) if method == "barnes_hut" else \
             f"x{world}: body-index shards of the all-pairs kernel, all-gather of 64-B rows"
     out = {
@@ -352,6 +356,10 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
                    "parallelism": par},
     }
 
+    if use_dist and method == "barnes_hut" and shard_mode == "let" and rank == 0:
+        e = sharded.engine
+        out["exchange"] = {"bytes_sent_per_step_rank0": int(e.wire_bytes), "bodies_migrated_last_step_rank0": int(e.migrated),
+                           "received_tree_rows_rank0": [int(c) for c in e.let_counts], "owned_bodies_rank0": int(sim.n)}
     if world == 1 and rank == 0 and not use_dist:
         # second pass with per-phase HIP events on the library stream (same K steps)
         sim.enable_timers(True)

@@ -136,29 +136,48 @@ int nbmi_set_shard(nbmi_sim *sim, int64_t begin, int64_t end);
 int nbmi_export_shard(nbmi_sim *sim, void *dev_rows);                              /* (end-begin, 8) f64 */
 int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_t end);
 
-/* Multi-GPU, experimental second form ("run exchange"; see DESIGN.md section 6 for why it is not
- * the default: fixed ownership without body migration degrades the walk).  Each rank's handle is created with nbmi_create over
- * the bodies it OWNS (a fixed set; any n_r >= 0) and never sees other ranks' velocities.  Per step
- * the host framework runs two collectives on device buffers between three library calls:
+/* Multi-GPU stage 2, "owner mode" (BASELINE north_star: bodies shard by Morton range, exchange of the upper /
+ * locally essential octree cells).  A rank's handle holds only the bodies whose octant key falls into the
+ * rank's key range (rebalanced every step), builds the octree of THOSE bodies inside the GLOBAL root cube
+ * (compute_bounds over the whole system, simulation.py:308-317) and walks its own tree plus, behind it in the
+ * same node array, the part of every other rank's tree that some body of this rank can open (the other ranks
+ * prune their trees against this rank's bounding box with the reference's own opening test, made conservative
+ * by 1e-9).  Per-rank sort / build / memory no longer grow with the number of ranks.  Cells that straddle a
+ * rank boundary are seen as one partial cell per rank instead of one whole cell, so positions agree with
+ * the single-GPU run to a tolerance (measured 1e-9 relative after 5 steps at 100 k bodies), not bit for bit;
+ * the replicated-tree exchange above (nbmi_set_shard) stays as the bit-exact mode.
  *
- *   nbmi_exchange_maxabs(h, m)            m <- max |coordinate| of the owned bodies (1 double)
- *        all-reduce MAX of m              (compute_bounds over the whole system, simulation.py:308-317)
- *   nbmi_exchange_export(h, m, run, R)    keys + local sort of the owned bodies; run <- R 32-byte
- *                                         records {key_hi, key_lo, x, y, z, G*m (fp32)} in key order,
- *                                         padded with all-ones keys after the n_r real ones
- *        all-gather of the runs           (world x R records)
- *   nbmi_exchange_step(h, runs, W, R, dt) merge the W sorted runs (by ranking), build the octree of the whole
- *                                         system from them, walk + integrate the owned bodies
+ * One step, host side (buffers are DEVICE pointers; the collectives are the host framework's):
+ *   nbmi_owner_maxabs(h, m)                         m <- max |coordinate| of the owned bodies (1 double)
+ *        all-reduce MAX of m
+ *   nbmi_owner_sample(h, m, samples, S)             keys of the owned bodies in the global cube; S regular samples
+ *        all-gather of the samples                  (world x S keys)
+ *   nbmi_owner_partition(h, all, world*S, send, counts)   splitters at equal quantiles; rows {x,y,z,vx,vy,vz,m,id}
+ *                                                   grouped by destination rank into `send`; counts[world] on the host
+ *        all-to-all of the counts, all-to-all-v of the rows  (only bodies that crossed a splitter travel)
+ *   nbmi_owner_adopt(h, recv, n_new, m, box)        the received rows become the owned bodies: keys, sort, octree;
+ *                                                   box <- their bounding box (6 doubles)
+ *        all-gather of the boxes                    (world x 6 doubles)
+ *   nbmi_owner_export_let(h, boxes, let, &count)    prune the own tree against the other ranks' boxes into `let`:
+ *                                                   let_capacity rows of 24-byte nodes, then let_capacity 32-byte rows
+ *                                                   of their float64 twins; count on the host
+ *        all-gather of the counts and of `let`      (world x let_capacity x 56 B, `count` rows of each used)
+ *   nbmi_owner_step(h, lets, counts, dt)            append the received trees behind the own one, walk, kick-drift
  *
- * The octree equals the single-GPU one (same sorted sequence of fp32 bodies), a body's force does not
- * depend on which bodies share its wave, so positions are bit-identical to a one-GPU run.
- * nbmi_exchange_enable allocates the whole-system tree workspace; afterwards nbmi_step,
- * nbmi_build_tree and nbmi_get_accelerations_f64 are refused on this handle.  Getters keep returning
- * the owned bodies in the order they were passed to nbmi_create.  Pointers are DEVICE pointers. */
-int nbmi_exchange_enable(nbmi_sim *sim, int64_t n_total, int world, int64_t run_rows);
-int nbmi_exchange_maxabs(nbmi_sim *sim, void *dev_maxabs);
-int nbmi_exchange_export(nbmi_sim *sim, const void *dev_maxabs, void *dev_run, int64_t run_rows);
-int nbmi_exchange_step(nbmi_sim *sim, const void *dev_runs, int world, int64_t run_rows, double dt);
+ * Getters of an owner handle return the owned bodies in their current (key) order; nbmi_owner_get_ids gives the
+ * global body ids of those rows. */
+nbmi_sim *nbmi_create_owner(int64_t n, const double *positions_xyz, const double *velocities_xyz, const double *masses,
+                            const int32_t *global_ids, int64_t capacity, int64_t let_capacity, int world, int rank,
+                            double G, double softening, double damping, double theta, int device);
+int64_t nbmi_owner_count(nbmi_sim *sim);
+int nbmi_owner_get_ids(nbmi_sim *sim, int32_t *out);
+int nbmi_owner_maxabs(nbmi_sim *sim, void *dev_maxabs);
+int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples);
+int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
+                         int64_t *counts_host);
+int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_bbox6);
+int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *count_host);
+int nbmi_owner_step(nbmi_sim *sim, const void *dev_lets, const int64_t *counts_host, double dt);
 
 /* Render-side reduction: NBodySimulation._compute_visibility + the gather of
  * draw() on the device (nbody/simulation.py:880-903, 927-928).  Frustum test of

@@ -112,7 +112,7 @@ def test_rccl_one_rank_group_stream_ordered_exchange(gpu):
 
 
 class _ThreadComm:
-    """all_reduce_max / all_gather between `world` Python threads that play the ranks."""
+    """The collectives of nbody.sharded.LetBarnesHut between `world` Python threads that play the ranks."""
 
     def __init__(self, world):
         import threading
@@ -122,51 +122,51 @@ class _ThreadComm:
         comm = self
 
         class Bound:
+            def _swap(self, mine):
+                comm.slots[rank] = mine
+                comm.bar.wait()
+                got = list(comm.slots)
+                comm.bar.wait()
+                return got
+
             def all_reduce_max(self, t):
                 import torch
-                comm.slots[rank] = t
-                comm.bar.wait()
-                m = torch.stack(list(comm.slots)).max(dim=0).values.clone()
-                comm.bar.wait()
+                m = torch.stack(self._swap(t.clone())).max(dim=0).values
                 t.copy_(m)
+                torch.cuda.synchronize()
                 comm.bar.wait()
 
             def all_gather(self, full, mine):
                 import torch
-                comm.slots[rank] = mine
+                full.copy_(torch.cat(self._swap(mine), dim=0))
+                torch.cuda.synchronize()
                 comm.bar.wait()
-                full.copy_(torch.cat(list(comm.slots), dim=0))
+
+            def all_to_all_counts(self, send_counts):
+                return np.array([c[rank] for c in self._swap(np.array(send_counts))], dtype=np.int64)
+
+            def all_gather_counts(self, mine):
+                return np.array(self._swap(int(mine)), dtype=np.int64)
+
+            def all_to_all_rows(self, recv, send, recv_counts, send_counts):
+                import torch
+                got = self._swap((send, np.array(send_counts)))
+                off = 0
+                for j in range(comm.world):
+                    sj, cj = got[j]
+                    start, c = int(cj[:rank].sum()), int(cj[rank])
+                    assert c == int(recv_counts[j])
+                    recv[off:off + c].copy_(sj[start:start + c])
+                    off += c
                 torch.cuda.synchronize()
                 comm.bar.wait()
 
         return Bound()
 
 
-def test_run_exchange_ranks_bit_identical_to_single_handle(gpu, monkeypatch):
-    """Run exchange (fixed ownership, sorted runs all-gathered, merged, whole-system octree per rank):
-    three threads on one GPU play three ranks through RunExchangeBarnesHut.step itself, collectives
-    replaced by thread barriers.  Owned bodies must equal the one-handle run bit for bit."""
+def _run_ranks(steppers, comm, dt, steps):
     import threading
-    from nbody.gpu_backend import HIPBarnesHutSimulation
-    from nbody.sharded import HipRunEngine, RunExchangeBarnesHut
-    # the small-system split walk adds a body's partial sums per node range instead of one running sum;
-    # the exchange handles never use it, so switch it off for the comparison
-    monkeypatch.setenv("NBMI_SPLIT_WAVES", "0")
-    g = golden("tree_collision_2048")
-    n = 2001  # ragged: the last rank owns fewer bodies, its run is padded
-    pos, vel, mass = g["pos"][:n], g["vel"][:n], g["mass"][:n] * np.linspace(0.5, 2.0, n)
-    G, eps = float(g["G"]), float(g["eps"])
-    world, steps, dt = 3, 6, 0.05
-    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
-    single.step_many(dt, steps)
-    ref_p, ref_v = single.get_positions_f64(), single.get_velocities()
-    stats = single.tree_stats()
-
-    comm = _ThreadComm(world)
-    engines = [HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, r, world) for r in range(world)]
-    assert sorted(np.concatenate([e.ids for e in engines]).tolist()) == list(range(n))
-    steppers = [RunExchangeBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
-    assert steppers[0].full.shape == (steppers[0].per * world, 4)
+    world = len(steppers)
     out, errs = [None] * world, []
 
     def rank_main(r):
@@ -179,56 +179,69 @@ def test_run_exchange_ranks_bit_identical_to_single_handle(gpu, monkeypatch):
 
     ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     [t.start() for t in ts]
-    [t.join(120) for t in ts]
+    [t.join(300) for t in ts]
     assert not errs, errs
-    for e in engines:
-        ids, p, v = e.owned_state()
-        assert np.array_equal(p, ref_p[ids]) and np.array_equal(v, ref_v[ids])
-        # every rank built the octree of the whole system
-        st = e.sim.tree_stats()
-        assert (st["num_nodes"], st["max_depth"], st["bounds"]) == (stats["num_nodes"], stats["max_depth"], stats["bounds"])
-    for r in range(world):
-        assert np.array_equal(out[r][0], ref_p) and np.array_equal(out[r][1], ref_v)
-    # an exchange handle refuses the single-GPU entry points
-    with pytest.raises(RuntimeError, match="run-exchange"):
-        engines[0].sim.step(dt)
-    # world 1 goes through the same calls with no collective
-    one = RunExchangeBarnesHut(HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, 0, 1), 0, 1)
-    one.step(dt, steps)
-    p1, v1 = one.gather_state()
-    assert np.array_equal(p1, ref_p) and np.array_equal(v1, ref_v)
+    return out
 
 
-def test_run_exchange_100k_two_ranks(gpu, monkeypatch):
-    """Bigger case through the merge path (runs of 50 k records, two ranks, sequential phases)."""
-    import torch
-    monkeypatch.setenv("NBMI_SPLIT_WAVES", "0")  # see the test above
+def test_owner_mode_three_ranks_agree_with_single_handle(gpu):
+    """Multi-GPU stage 2 (north_star form): owned key ranges, body migration, per-rank octrees inside the global
+    cube, pruned trees exchanged.  Three threads on one GPU play three ranks through LetBarnesHut.step itself.
+    Cells straddling rank boundaries are partial cells here, so the comparison with the single handle is a
+    tolerance: <= 1e-6 of the largest coordinate after 5 steps (measured ~1e-9)."""
     from nbody.gpu_backend import HIPBarnesHutSimulation
-    from nbody.sharded import HipRunEngine, RunExchangeBarnesHut
+    from nbody.sharded import HipLetEngine, LetBarnesHut
     from tools.presets import generate_distribution
     np.random.seed(7)
-    pos, vel, mass = generate_distribution("galaxy", 100_000, 500.0, 0.15)
-    G, eps = 0.15, 3.0
-    world, dt = 2, 0.05
-    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
-    single.step_many(dt, 3)
-    ref_p = single.get_positions_f64()
-    engines = [HipRunEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, r, world) for r in range(world)]
-    st = [RunExchangeBarnesHut(e, r, world, None) for r, e in enumerate(engines)]
-    for _ in range(3):
-        for s in st:
-            s.engine.local_maxabs(s.maxabs)
-        m = torch.stack([s.maxabs for s in st]).max(dim=0).values
-        for s in st:
-            s.maxabs.copy_(m)
-            s.engine.export_run(s.maxabs, s.mine)
-        full = torch.cat([s.mine for s in st], dim=0)
-        for s in st:
-            s.engine.step_runs(full, dt)
+    n = 60_001
+    pos, vel, mass = generate_distribution("galaxy", n, 500.0, 0.15)
+    mass = mass * np.random.uniform(0.5, 1.5, n)
+    G, eps, theta = 0.15, 3.0, 0.5
+    world, steps, dt = 3, 5, 0.05
+    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, theta)
+    single.step_many(dt, steps)
+    ref_p, ref_v = single.get_positions_f64(), single.get_velocities()
+    own_nodes = single.tree_stats()["num_nodes"]
+
+    comm = _ThreadComm(world)
+    engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
+    steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    out = _run_ranks(steppers, comm, dt, steps)
+    scale = np.abs(ref_p).max()
+    for r in range(world):
+        err = np.abs(out[r][0] - ref_p).max() / scale
+        verr = np.abs(out[r][1] - ref_v).max() / np.abs(ref_v).max()
+        print(f"rank {r}: owns {engines[r].sim.n} bodies, received tree rows {engines[r].let_counts.tolist()} "
+              f"(single-GPU tree {own_nodes}), sent {engines[r].wire_bytes} B, migrated {engines[r].migrated}; "
+              f"pos err {err:.2e} vel err {verr:.2e}")
+        assert err <= 1e-6 and verr <= 1e-4
+        assert np.array_equal(out[r][0], out[0][0])  # every rank gathered the same state
+    counts = [e.sim.n for e in engines]
+    assert sum(counts) == n and max(counts) <= 1.1 * n / world + 64  # re-balanced by the sampled splitters
+    # a rank ships a pruned tree, not its whole tree
     for e in engines:
-        ids, p, _ = e.owned_state()
-        assert np.array_equal(p, ref_p[ids])
-    assert engines[0].sim.tree_stats()["num_nodes"] == single.tree_stats()["num_nodes"]
+        assert 0 < e.let_counts[(e.rank + 1) % world] < 0.8 * 1.5 * max(counts)
+    # an owner handle refuses the single-GPU entry points
+    with pytest.raises(RuntimeError, match="owner mode"):
+        engines[0].sim.step(dt)
+    for e in engines:
+        e.sim.close()
+
+
+def test_owner_mode_one_rank_is_the_single_handle(gpu):
+    """World size 1 goes through the same calls with no collective and must equal the plain handle bit for bit."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    g = golden("tree_collision_2048")
+    n = 2001
+    pos, vel, mass = g["pos"][:n], g["vel"][:n], g["mass"][:n] * np.linspace(0.5, 2.0, n)
+    G, eps = float(g["G"]), float(g["eps"])
+    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, 0.5)
+    single.step_many(0.05, 6)
+    one = LetBarnesHut(HipLetEngine(pos, vel, mass, G, eps, 1.0, 0.5, 0, 0, 1), 0, 1)
+    one.step(0.05, 6)
+    p1, v1 = one.gather_state()
+    assert np.array_equal(p1, single.get_positions_f64()) and np.array_equal(v1, single.get_velocities())
 
 
 def test_record_writes_reference_format_and_resumes(gpu, tmp_path, oracle):
