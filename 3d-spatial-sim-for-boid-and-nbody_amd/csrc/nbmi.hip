@@ -1407,15 +1407,18 @@ __global__ __launch_bounds__(kBlock) void k_pack_rows_perm(Bodies cur, const uin
     o[6] = cur.m[r]; o[7] = (double)cur.id[r];
 }
 
-// bounding box of the bodies: per-block partials, then one block
-__global__ __launch_bounds__(kBlock) void k_bbox_blocks(const double *__restrict__ x, const double *__restrict__ y,
-                                                        const double *__restrict__ z, int64_t n, double *__restrict__ part) {
+// Where a rank's bodies are: kBoxesPerRank bounding boxes, one per equal chunk of its key-sorted bodies.  (ONE
+// box per rank prunes almost nothing: a key range is a union of a few cells of different levels, and its
+// bounding box easily covers the whole system.  A chunk of a key range is compact.)  One workgroup per chunk.
+constexpr int kBoxesPerRank = 16;
+__global__ __launch_bounds__(kBlock) void k_bbox_chunks(const double4 *__restrict__ p64_s, int64_t n, double *__restrict__ out) {
     __shared__ double red[6][kBlock / 64];
+    const int64_t b0 = n * blockIdx.x / kBoxesPerRank, b1 = n * (blockIdx.x + 1) / kBoxesPerRank;
     double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        const double a = x[i], b = y[i], c = z[i];
-        v[0] = fmin(v[0], a); v[1] = fmin(v[1], b); v[2] = fmin(v[2], c);
-        v[3] = fmax(v[3], a); v[4] = fmax(v[4], b); v[5] = fmax(v[5], c);
+    for (int64_t i = b0 + threadIdx.x; i < b1; i += kBlock) {
+        const double4 q = p64_s[i];
+        v[0] = fmin(v[0], q.x); v[1] = fmin(v[1], q.y); v[2] = fmin(v[2], q.z);
+        v[3] = fmax(v[3], q.x); v[4] = fmax(v[4], q.y); v[5] = fmax(v[5], q.z);
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -1431,15 +1434,8 @@ __global__ __launch_bounds__(kBlock) void k_bbox_blocks(const double *__restrict
         const int k = threadIdx.x;
         double r = red[k][0];
         for (int w = 1; w < kBlock / 64; w++) r = k < 3 ? fmin(r, red[k][w]) : fmax(r, red[k][w]);
-        part[6 * blockIdx.x + k] = r;
+        out[6 * blockIdx.x + k] = r;  // an empty chunk leaves lo = +inf > hi = -inf
     }
-}
-__global__ void k_bbox_final(const double *__restrict__ part, int blocks, double *__restrict__ out6) {
-    const int k = threadIdx.x;
-    if (k >= 6) return;
-    double r = part[k];
-    for (int b = 1; b < blocks; b++) r = k < 3 ? fmin(r, part[6 * b + k]) : fmax(r, part[6 * b + k]);
-    out6[k] = r;
 }
 
 // ---- plain int32 exclusive scan (three phases, like the moment scan) ---------------------------
@@ -1514,9 +1510,9 @@ __global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restric
 }
 
 // ---- locally essential tree -----------------------------------------------------------------
-// A cell can only be opened by a body of another rank if the opening test can fail somewhere in that rank's
-// bounding box; if it cannot (for any other rank), nobody else ever looks below it and its subtree stays
-// home.  Conservative by a 1e-9 margin on both sides of the float64 test.  diff[] marks the dropped
+// A cell can only be opened by a body of another rank if the opening test can fail somewhere in one of that
+// rank's bounding boxes; if it cannot (for any other rank), nobody else ever looks below it and its subtree
+// stays home.  Conservative by a 1e-9 margin on both sides of the float64 test.  diff[] marks the dropped
 // pre-order ranges (+1 at the first node of the subtree, -1 behind it): a node is kept iff the running sum
 // over diff up to and including it is zero.
 __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
@@ -1530,10 +1526,10 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
     const double size = c.hs * 2.0;
     bool needed = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
     const double thr = needed ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
-    for (int j = 0; j < world && !needed; j++) {
-        if (j == me) continue;
+    for (int j = 0; j < world * kBoxesPerRank && !needed; j++) {
+        if (j / kBoxesPerRank == me) continue;
         const double *b = boxes + 6 * j;
-        if (!(b[0] <= b[3])) continue;  // that rank owns nothing
+        if (!(b[0] <= b[3])) continue;  // an empty chunk
         const double dx = fmax(0.0, fmax(b[0] - c.cx, c.cx - b[3]));
         const double dy = fmax(0.0, fmax(b[1] - c.cy, c.cy - b[4]));
         const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
@@ -1642,7 +1638,6 @@ struct nbmi_sim {
     uint64_t *let_split = nullptr;
     uint32_t *let_dest = nullptr, *let_dest_s = nullptr, *let_order = nullptr;
     int64_t *let_counts = nullptr;
-    double *let_bbox = nullptr;
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr;
     // render-side reduction scratch (nbmi_visible_points), allocated on first use
     uint8_t *vis_flag = nullptr;
@@ -2439,7 +2434,7 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
     if (rc == 0) {
         const int64_t c = s->cap, rows = s->node_capacity + 2;
         if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) || dev_alloc(s, &s->let_dest_s, c) ||
-            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, kMaxWorld) || dev_alloc(s, &s->let_bbox, 6 * 256) ||
+            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, kMaxWorld) ||
             dev_alloc(s, &s->let_diff, rows) || dev_alloc(s, &s->let_scan, rows) || dev_alloc(s, &s->let_keep, rows) ||
             dev_alloc(s, &s->let_tiles, rows / kScanTile + 4))
             rc = -2;
@@ -2462,6 +2457,7 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
 }
 
 int64_t nbmi_owner_count(nbmi_sim *s) { return s ? s->n : -1; }
+int nbmi_owner_boxes_per_rank(void) { return kBoxesPerRank; }
 
 int nbmi_owner_get_ids(nbmi_sim *s, int32_t *out) {
     if (int rc = owner_check(s, "nbmi_owner_get_ids")) return rc;
@@ -2522,14 +2518,14 @@ int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_sam
     return 0;
 }
 
-int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_bbox6) {
+int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_boxes) {
     if (int rc = owner_check(s, "nbmi_owner_adopt")) return rc;
     if (n_new < 0 || n_new > s->cap) {
         nbmi::set_error("nbmi_owner_adopt: %lld bodies do not fit the capacity of %lld (raise the head room)", (long long)n_new,
                         (long long)s->cap);
         return NBMI_ERR_CAPACITY;
     }
-    if ((n_new > 0 && !dev_recv_rows) || !dev_maxabs || !dev_bbox6) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
+    if ((n_new > 0 && !dev_recv_rows) || !dev_maxabs || !dev_boxes) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
     hipStream_t st = s->stream;
     s->n = n_new; s->nt = n_new; s->shard_begin = 0; s->shard_end = n_new;
     Bodies cur = s->buf[s->curbuf];
@@ -2540,13 +2536,12 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, cons
     if (n_new > 0) {
         if (int rc = enqueue_local_sort(s, -1)) return rc;
         if (int rc = enqueue_global_tree(s)) return rc;
-        int gb = nblocks(n_new);
-        if (gb > 256) gb = 256;
-        k_bbox_blocks<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n_new, s->let_bbox);
-        k_bbox_final<<<1, 64, 0, st>>>(s->let_bbox, gb, (double *)dev_bbox6);
+        k_bbox_chunks<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, n_new, (double *)dev_boxes);
     } else {
-        const double empty[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        NBMI_HIP_CHECK(hipMemcpyAsync(dev_bbox6, empty, sizeof(empty), hipMemcpyHostToDevice, st));
+        double empty[6 * kBoxesPerRank];
+        for (int k = 0; k < 6 * kBoxesPerRank; k++) empty[k] = (k % 6) < 3 ? INFINITY : -INFINITY;
+        NBMI_HIP_CHECK(hipMemcpyAsync(dev_boxes, empty, sizeof(empty), hipMemcpyHostToDevice, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));  // `empty` is a stack object
     }
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipStreamSynchronize(st));

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "nbmi_get_order": (C.c_int, [_vp, _vp]),
     "nbmi_create_owner": (_vp, [_i64, _vp, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _dbl, _dbl, _dbl, _dbl, C.c_int]),
     "nbmi_owner_count": (_i64, [_vp]),
+    "nbmi_owner_boxes_per_rank": (C.c_int, []),
     "nbmi_owner_get_ids": (C.c_int, [_vp, _vp]),
     "nbmi_owner_maxabs": (C.c_int, [_vp, _vp]),
     "nbmi_owner_sample": (C.c_int, [_vp, _vp, _vp, C.c_int]),

@@ -160,10 +160,10 @@ def create_sharded_simulation(positions, velocities, masses, G, softening, dampi
 def let_capacities(n_total, world):
     """(body capacity, rows of one locally essential tree) of a rank: 25 % head room over the equal share
     (the splitters re-balance every step, so the share only drifts by sampling noise) and, for the tree a
-    rank sends to the others, a generous fraction of its own ~1.5 n nodes (measured: 3-12 %)."""
+    rank sends to the others, two thirds of its own ~1.5 n nodes (measured at 1 M bodies per rank: see DESIGN section 6)."""
     share = (n_total + world - 1) // world
     cap = int(share * 1.25) + 4096
-    let = 0 if world == 1 else int(0.6 * share) + 65536
+    let = 0 if world == 1 else int(1.0 * share) + 65536
     return cap, let
 
 
@@ -201,8 +201,9 @@ class HipLetEngine:
         self.all_samples = z(world * self.SAMPLES, dtype=i64)
         self.send_rows = z(cap, ROW)
         self.recv_rows = z(cap, ROW)
-        self.bbox = z(6)
-        self.boxes = z(world * 6)
+        nbox = 6 * int(self.sim._lib.nbmi_owner_boxes_per_rank())  # several boxes per rank: a key range is not a box
+        self.bbox = z(nbox)
+        self.boxes = z(world * nbox)
         let_bytes = let * 56  # 24-byte walk record + 32-byte float64 twin
         self.let_mine = torch.zeros(max(let_bytes, 8), dtype=torch.uint8, device=self.device)
         self.let_all = torch.zeros(max(let_bytes, 8) * world, dtype=torch.uint8, device=self.device)
@@ -290,7 +291,7 @@ class LetBarnesHut:
                 counts = self.comm.all_gather_counts(mine)
                 self.comm.all_gather(e.let_all, e.let_mine)
                 e.wait()
-                wire += 48 + mine * e.LET_ROW_BYTES
+                wire += e.bbox.numel() * 8 + mine * e.LET_ROW_BYTES
             e.op_step(counts, dt)
             e.let_counts = counts
             e.wire_bytes = wire

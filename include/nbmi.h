@@ -156,8 +156,9 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *                                                   grouped by destination rank into `send`; counts[world] on the host
  *        all-to-all of the counts, all-to-all-v of the rows  (only bodies that crossed a splitter travel)
  *   nbmi_owner_adopt(h, recv, n_new, m, box)        the received rows become the owned bodies: keys, sort, octree;
- *                                                   box <- their bounding box (6 doubles)
- *        all-gather of the boxes                    (world x 6 doubles)
+ *                                                   box <- B = nbmi_owner_boxes_per_rank() bounding boxes (6 doubles
+ *                                                   each: lo xyz, hi xyz), one per equal chunk of the key order
+ *        all-gather of the boxes                    (world x B x 6 doubles)
  *   nbmi_owner_export_let(h, boxes, let, &count)    prune the own tree against the other ranks' boxes into `let`:
  *                                                   let_capacity rows of 24-byte nodes, then let_capacity 32-byte rows
  *                                                   of their float64 twins; count on the host
@@ -170,12 +171,13 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *positions_xyz, const double
                             const int32_t *global_ids, int64_t capacity, int64_t let_capacity, int world, int rank,
                             double G, double softening, double damping, double theta, int device);
 int64_t nbmi_owner_count(nbmi_sim *sim);
+int nbmi_owner_boxes_per_rank(void);
 int nbmi_owner_get_ids(nbmi_sim *sim, int32_t *out);
 int nbmi_owner_maxabs(nbmi_sim *sim, void *dev_maxabs);
 int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples);
 int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
                          int64_t *counts_host);
-int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_bbox6);
+int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_boxes);
 int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *count_host);
 int nbmi_owner_step(nbmi_sim *sim, const void *dev_lets, const int64_t *counts_host, double dt);
 

@@ -1,0 +1,98 @@
+"""Multi-GPU stage 2 on ONE GPU: W owner-mode handles play W ranks, phase by phase (collectives = torch ops on the
+device), weak scaling with `per` bodies per rank.  Reports rank 0's time per phase (host clock around the
+library call + stream sync), the size of the trees it receives, the rows that migrate and the bytes it sends.
+Shows what the north-star exchange costs per rank as W grows: sort / build stay flat, the walk grows with the
+received trees.  python scripts/gpu_let_probe.py [per] [Ws]"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+importlib.import_module("3d-spatial-sim-for-boid-and-nbody_amd")
+from nbody.gpu_backend import HIPBarnesHutSimulation  # noqa: E402
+from nbody.sharded import ROW, HipLetEngine  # noqa: E402
+from tools.presets import generate_distribution  # noqa: E402
+
+per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+Ws = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+G, eps, theta, dt, steps = 0.07, 1.5, 0.5, 0.05, 4
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return out, 1e3 * (time.perf_counter() - t0)
+
+
+for W in Ws:
+    n = per * W
+    np.random.seed(42)
+    p, v, m = generate_distribution("galaxy", n, 800.0 * W ** (1 / 3), G)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        E = [HipLetEngine(p, v, m, G, eps, 1.0, theta, 0, r, W) for r in range(W)]
+    ph = {k: 0.0 for k in ("maxabs", "sample", "partition", "adopt_sort_build", "export_tree", "walk")}
+    for it in range(steps):
+        rec = it >= 1  # first step: initial migration
+        for e in E:
+            _, t = timed(e.op_maxabs)
+            if rec and e.rank == 0: ph["maxabs"] += t
+        mx = torch.stack([e.maxabs for e in E]).max(dim=0).values
+        for e in E:
+            e.maxabs.copy_(mx)
+            _, t = timed(e.op_sample)
+            if rec and e.rank == 0: ph["sample"] += t
+        alls = torch.cat([e.samples for e in E])
+        sc = []
+        for e in E:
+            c, t = timed(lambda: e.op_partition(alls))
+            sc.append(c)
+            if rec and e.rank == 0: ph["partition"] += t
+        for e in E:
+            off = 0
+            for j in range(W):
+                start, c = int(sc[j][:e.rank].sum()), int(sc[j][e.rank])
+                e.recv_rows[off:off + c].copy_(E[j].send_rows[start:start + c])
+                off += c
+            _, t = timed(lambda: e.op_adopt(e.recv_rows, off))
+            if rec and e.rank == 0: ph["adopt_sort_build"] += t
+            e.migrated = int(sc[e.rank].sum() - sc[e.rank][e.rank])
+        boxes = torch.cat([e.bbox for e in E])
+        counts = np.zeros(W, dtype=np.int64)
+        if W > 1:
+            for e in E:
+                e.boxes.copy_(boxes)
+                c, t = timed(e.op_export_let)
+                counts[e.rank] = c
+                if rec and e.rank == 0: ph["export_tree"] += t
+            let_all = torch.cat([e.let_mine for e in E])
+        for e in E:
+            if W > 1:
+                e.let_all.copy_(let_all)
+            _, t = timed(lambda: (e.op_step(counts, dt), e.sim.sync()))
+            if rec and e.rank == 0: ph["walk"] += t
+    k = steps - 1
+    own_nodes = E[0].sim.tree_stats(depth=False)["num_nodes"]
+    row = {"world": W, "bodies_per_rank": per, "rank0_ms": {a: round(b / k, 3) for a, b in ph.items()},
+           "rank0_ms_total": round(sum(ph.values()) / k, 3), "rank0_owned": E[0].sim.n, "rank0_own_tree_nodes": own_nodes,
+           "tree_rows_received_by_rank0": int(counts.sum() - counts[0]), "tree_rows_sent_by_rank0": int(counts[0]),
+           "rows_migrated_from_rank0": E[0].migrated,
+           "bytes_sent_by_rank0": int(counts[0]) * 56 + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
+    if W == Ws[0] and W == 1:
+        single = HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta)
+        single.step_many(dt, 2); single.sync()
+        _, t = timed(lambda: (single.step_many(dt, 5), single.sync()))
+        row["plain_single_handle_ms_per_step"] = round(t / 5, 3)
+        single.close()
+    print(json.dumps(row), flush=True)
+    for e in E:
+        e.sim.close()
+    del E
