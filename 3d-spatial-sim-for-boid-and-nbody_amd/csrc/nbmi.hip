@@ -1407,13 +1407,65 @@ __global__ __launch_bounds__(kBlock) void k_pack_rows_perm(Bodies cur, const uin
     o[6] = cur.m[r]; o[7] = (double)cur.id[r];
 }
 
-// Where a rank's bodies are: kBoxesPerRank bounding boxes, one per equal chunk of its key-sorted bodies.  (ONE
-// box per rank prunes almost nothing: a key range is a union of a few cells of different levels, and its
-// bounding box easily covers the whole system.  A chunk of a key range is compact.)  One workgroup per chunk.
-constexpr int kBoxesPerRank = 16;
-__global__ __launch_bounds__(kBlock) void k_bbox_chunks(const double4 *__restrict__ p64_s, int64_t n, double *__restrict__ out) {
+// Where a rank's bodies are, for the pruning of the trees the others send it: tight bounding boxes of the
+// bodies inside octree cells of the rank's OWN tree - the cells of level kBoxLevel, refined down to
+// kBoxLevelMax along the two cells that hold the rank's first and last body (a rank's key range ends in the
+// middle of cells; unrefined, those two boxes would overlap the neighbours' whole working set).  (Bounding
+// boxes of equal chunks of the key order do not work: a chunk that crosses a high-level cell boundary spans
+// two distant corners of the system, and one such box keeps everything alive.)  The boxes come out in key
+// order (slot = exclusive scan of the emit flags over the pre-order array), so every kSuper consecutive ones
+// are neighbours in space and get a common "super box" for a two-level test.
+constexpr int kBoxLevel = 4, kBoxLevelMax = 11;
+constexpr int kBoxesPerRank = 2048, kSuper = 32, kSupersPerRank = kBoxesPerRank / kSuper;
+
+// flag[i] = 1 if node i is one of the cells / leaves whose bodies get a box
+__global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
+                                                      const int32_t *__restrict__ node_ref, const uint64_t *__restrict__ hi_s,
+                                                      const uint64_t *__restrict__ lo_s, int64_t num_nodes, int64_t n,
+                                                      int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_nodes) return;
+    const int l = node_level[i];
+    int f = 0;
+    if (l <= kBoxLevelMax) {
+        const Node nd = nodes[i];
+        const bool leaf = __float_as_int(nd.s2t) == 0;
+        const int64_t a = node_ref[i];
+        const int64_t nx = nd.next_off / kNodeBytes;
+        const int64_t b = nx < num_nodes ? node_ref[nx] : n;
+        const bool boundary = a == 0 || b == n;  // holds the rank's first or last body
+        if (l < kBoxLevel) {
+            f = leaf ? 1 : 0;
+        } else if (l == kBoxLevel) {
+            f = (!boundary || leaf) ? 1 : 0;
+        } else {
+            // only below the two boundary chains: the parent (level l - 1) holds body 0 or body n - 1
+            const uint64_t h = hi_s[a], lo = lo_s[a];
+            const bool under = cpl_digits(h, lo, hi_s[0], lo_s[0]) >= l - 1 || cpl_digits(h, lo, hi_s[n - 1], lo_s[n - 1]) >= l - 1;
+            f = (under && (!boundary || leaf || l == kBoxLevelMax)) ? 1 : 0;
+        }
+    }
+    flag[i] = f;
+}
+// body ranges of the flagged nodes, in key order
+__global__ __launch_bounds__(kBlock) void k_box_ranges(const Node *__restrict__ nodes, const int32_t *__restrict__ node_ref,
+                                                       const int32_t *__restrict__ flag, const int32_t *__restrict__ slot,
+                                                       int64_t num_nodes, int64_t n, int32_t *__restrict__ ranges /* 2 x kBoxesPerRank */) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= num_nodes || !flag[i]) return;
+    const int k = slot[i];
+    if (k >= kBoxesPerRank) return;  // more cells than boxes: the last box takes everything from its cell on
+    const int64_t nx = nodes[i].next_off / kNodeBytes;
+    ranges[2 * k] = node_ref[i];
+    ranges[2 * k + 1] = (k == kBoxesPerRank - 1 && slot[num_nodes] > kBoxesPerRank) ? (int32_t)n
+                                                                                    : (int32_t)(nx < num_nodes ? node_ref[nx] : n);
+}
+// one workgroup per box: tight bounding box of the bodies [a, b) (empty box: lo = +inf > hi = -inf)
+__global__ __launch_bounds__(kBlock) void k_range_boxes(const double4 *__restrict__ p64_s, const int32_t *__restrict__ ranges,
+                                                        const int32_t *__restrict__ total, double *__restrict__ out) {
     __shared__ double red[6][kBlock / 64];
-    const int64_t b0 = n * blockIdx.x / kBoxesPerRank, b1 = n * (blockIdx.x + 1) / kBoxesPerRank;
+    const int k = blockIdx.x;
+    const int64_t b0 = k < *total && k < kBoxesPerRank ? ranges[2 * k] : 0, b1 = k < *total && k < kBoxesPerRank ? ranges[2 * k + 1] : 0;
     double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = b0 + threadIdx.x; i < b1; i += kBlock) {
         const double4 q = p64_s[i];
@@ -1421,21 +1473,33 @@ __global__ __launch_bounds__(kBlock) void k_bbox_chunks(const double4 *__restric
         v[3] = fmax(v[3], q.x); v[4] = fmax(v[4], q.y); v[5] = fmax(v[5], q.z);
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int c = 0; c < 6; c++) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const double t = __shfl_xor(v[k], o);
-            v[k] = k < 3 ? fmin(v[k], t) : fmax(v[k], t);
+            const double t = __shfl_xor(v[c], o);
+            v[c] = c < 3 ? fmin(v[c], t) : fmax(v[c], t);
         }
-        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v[c];
     }
     __syncthreads();
     if (threadIdx.x < 6) {
-        const int k = threadIdx.x;
-        double r = red[k][0];
-        for (int w = 1; w < kBlock / 64; w++) r = k < 3 ? fmin(r, red[k][w]) : fmax(r, red[k][w]);
-        out[6 * blockIdx.x + k] = r;  // an empty chunk leaves lo = +inf > hi = -inf
+        const int c = threadIdx.x;
+        double r = red[c][0];
+        for (int w = 1; w < kBlock / 64; w++) r = c < 3 ? fmin(r, red[c][w]) : fmax(r, red[c][w]);
+        out[6 * k + c] = r;
     }
+}
+// super box = union of kSuper consecutive boxes (of every rank)
+__global__ void k_super_boxes(const double *__restrict__ boxes, int nsupers, double *__restrict__ supers) {
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nsupers) return;
+    double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < kSuper; k++) {
+        const double *b = boxes + 6 * ((int64_t)sidx * kSuper + k);
+        if (!(b[0] <= b[3])) continue;
+        for (int c = 0; c < 3; c++) { v[c] = fmin(v[c], b[c]); v[3 + c] = fmax(v[3 + c], b[3 + c]); }
+    }
+    for (int c = 0; c < 6; c++) supers[6 * sidx + c] = v[c];
 }
 
 // ---- plain int32 exclusive scan (three phases, like the moment scan) ---------------------------
@@ -1515,8 +1579,16 @@ __global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restric
 // stays home.  Conservative by a 1e-9 margin on both sides of the float64 test.  diff[] marks the dropped
 // pre-order ranges (+1 at the first node of the subtree, -1 behind it): a node is kept iff the running sum
 // over diff up to and including it is zero.
+__device__ __forceinline__ bool box_may_open(const double *__restrict__ b, const Node64 &c, double eps2, double thr) {
+    if (!(b[0] <= b[3])) return false;  // empty
+    const double dx = fmax(0.0, fmax(b[0] - c.cx, c.cx - b[3]));
+    const double dy = fmax(0.0, fmax(b[1] - c.cy, c.cy - b[4]));
+    const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
+    return (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9) <= thr;  // some point of the box may fail "size / dist < theta"
+}
 __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
-                                                     int64_t num_nodes, const double *__restrict__ boxes, int world, int me,
+                                                     int64_t num_nodes, const double *__restrict__ boxes,
+                                                     const double *__restrict__ supers, int world, int me,
                                                      double theta, double eps2, int32_t *__restrict__ diff) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_nodes) return;
@@ -1526,15 +1598,10 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
     const double size = c.hs * 2.0;
     bool needed = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
     const double thr = needed ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
-    for (int j = 0; j < world * kBoxesPerRank && !needed; j++) {
-        if (j / kBoxesPerRank == me) continue;
-        const double *b = boxes + 6 * j;
-        if (!(b[0] <= b[3])) continue;  // an empty chunk
-        const double dx = fmax(0.0, fmax(b[0] - c.cx, c.cx - b[3]));
-        const double dy = fmax(0.0, fmax(b[1] - c.cy, c.cy - b[4]));
-        const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
-        const double d2 = (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9);
-        if (d2 <= thr) needed = true;  // some point of the box may fail "size / dist < theta"
+    for (int sb = 0; sb < world * kSupersPerRank && !needed; sb++) {
+        if (sb / kSupersPerRank == me) continue;
+        if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
+        for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
     }
     if (!needed) {
         const int64_t nx = nd.next_off / kNodeBytes;
@@ -1638,7 +1705,8 @@ struct nbmi_sim {
     uint64_t *let_split = nullptr;
     uint32_t *let_dest = nullptr, *let_dest_s = nullptr, *let_order = nullptr;
     int64_t *let_counts = nullptr;
-    int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr;
+    int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
+    double *let_supers = nullptr;
     // render-side reduction scratch (nbmi_visible_points), allocated on first use
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
@@ -2436,7 +2504,8 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
         if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) || dev_alloc(s, &s->let_dest_s, c) ||
             dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, kMaxWorld) ||
             dev_alloc(s, &s->let_diff, rows) || dev_alloc(s, &s->let_scan, rows) || dev_alloc(s, &s->let_keep, rows) ||
-            dev_alloc(s, &s->let_tiles, rows / kScanTile + 4))
+            dev_alloc(s, &s->let_tiles, rows / kScanTile + 4) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
+            dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld))
             rc = -2;
     }
     if (rc == 0 && n > 0) {  // global ids instead of the row numbers k_split_state wrote
@@ -2536,12 +2605,24 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, cons
     if (n_new > 0) {
         if (int rc = enqueue_local_sort(s, -1)) return rc;
         if (int rc = enqueue_global_tree(s)) return rc;
-        k_bbox_chunks<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, n_new, (double *)dev_boxes);
+        // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags)
+        const int64_t rows = s->own_node_rows;  // the node count lives on the device: launch for the row budget
+        (void)rows;
+        TreeInfo h;
+        NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));
+        if (h.error) return check_device_error(s);
+        const int64_t nn = h.num_nodes;
+        k_box_flags<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, nn, n_new, s->let_keep);
+        if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan)) return rc;
+        NBMI_HIP_CHECK(hipMemsetAsync(s->let_ranges, 0, sizeof(int32_t) * 2 * kBoxesPerRank, st));
+        k_box_ranges<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, nn, n_new, s->let_ranges);
+        k_range_boxes<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, s->let_ranges, s->let_scan + nn, (double *)dev_boxes);
     } else {
-        double empty[6 * kBoxesPerRank];
+        std::vector<double> empty(6 * kBoxesPerRank);
         for (int k = 0; k < 6 * kBoxesPerRank; k++) empty[k] = (k % 6) < 3 ? INFINITY : -INFINITY;
-        NBMI_HIP_CHECK(hipMemcpyAsync(dev_boxes, empty, sizeof(empty), hipMemcpyHostToDevice, st));
-        NBMI_HIP_CHECK(hipStreamSynchronize(st));  // `empty` is a stack object
+        NBMI_HIP_CHECK(hipMemcpyAsync(dev_boxes, empty.data(), empty.size() * 8, hipMemcpyHostToDevice, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));  // `empty` dies here
     }
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipStreamSynchronize(st));
@@ -2561,8 +2642,10 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int
     if (h.error) return check_device_error(s);
     const int64_t nn = h.num_nodes;
     NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)(nn + 1) * 4, st));
-    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->world, s->rank, s->theta,
-                                              s->softening * s->softening, s->let_diff);
+    k_super_boxes<<<(s->world * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, s->world * kSupersPerRank,
+                                                                       s->let_supers);
+    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->world, s->rank,
+                                              s->theta, s->softening * s->softening, s->let_diff);
     if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan)) return rc;
     k_let_keep<<<nblocks(nn), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, s->let_keep);
     if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan)) return rc;
