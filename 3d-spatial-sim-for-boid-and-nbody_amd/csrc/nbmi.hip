@@ -1254,6 +1254,23 @@ __global__ __launch_bounds__(kBlock) void k_unperm3_f64(const double *__restrict
     const int64_t o = 3 * (id ? (int64_t)id[r] : r);
     out[o] = a[r]; out[o + 1] = b[r]; out[o + 2] = c[r];
 }
+// ---- frame codec on the device (tools/record.py:231-326) ------------------------------------------
+// Format-2 payload of a .zstd frame: int16((cur - prev) * 1000) against the PREVIOUS DECODED frame
+// (record.py:254-262; decoder :313-322), float32 arithmetic like NumPy's, C-cast wrap beyond +-32.767 kept
+// [quirk].  `prev` (float32, caller's body order) lives in HBM and is advanced to what the decoder will
+// reconstruct, prev + int16 / 1000, so only 6 bytes per body and array cross PCIe instead of 12.
+__global__ __launch_bounds__(kBlock) void k_frame_delta(const float *__restrict__ cur, float *__restrict__ prev, int64_t count,
+                                                        int16_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= count) return;
+    const float p = prev[i];
+    const float t = __fmul_rn(__fsub_rn(cur[i], p), 1000.0f);
+    // float -> int32 (truncation toward zero) -> low 16 bits: what ndarray.astype(np.int16) does on x86-64
+    const int16_t q = (int16_t)(int)t;
+    out[i] = q;
+    prev[i] = __fadd_rn(p, __fdiv_rn((float)q, 1000.0f));
+}
+
 __global__ __launch_bounds__(kBlock) void k_split_state(const double *__restrict__ pos, const double *__restrict__ vel,
                                                         const double *__restrict__ mass, Bodies cur, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1707,6 +1724,10 @@ struct nbmi_sim {
     int64_t *let_counts = nullptr;
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
     double *let_supers = nullptr;
+    // frame codec: previous decoded frame (positions then colours, float32, caller's order) and the int16 payload
+    float *frame_prev = nullptr;
+    int16_t *frame_q = nullptr;
+    bool frame_have_prev = false;
     // render-side reduction scratch (nbmi_visible_points), allocated on first use
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
@@ -2695,6 +2716,81 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_lets, const int64_t *counts, do
     if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
     s->curbuf ^= 1;
     s->tree_valid = false;
+    return 0;
+}
+
+
+// ---- frame codec ----------------------------------------------------------------
+namespace {
+int frame_current(nbmi_sim *s, float **d_pos) {  // float32 positions in the caller's order, in `stage`
+    const int64_t n = s->n;
+    Bodies cur = s->buf[s->curbuf];
+    float *dp = (float *)s->stage;
+    k_unperm3_f32<<<nblocks(n), kBlock, 0, s->stream>>>(cur.x, cur.y, cur.z, s->owner ? nullptr : cur.id, n, dp);
+    NBMI_HIP_CHECK(hipGetLastError());
+    *d_pos = dp;
+    return 0;
+}
+int frame_alloc(nbmi_sim *s) {
+    if (s->frame_prev) return 0;
+    const int64_t c = s->cap > s->n ? s->cap : s->n;
+    if (dev_alloc(s, &s->frame_prev, (size_t)6 * (c ? c : 1)) || dev_alloc(s, &s->frame_q, (size_t)6 * (c ? c : 1))) return NBMI_ERR_HIP;
+    return 0;
+}
+}  // namespace
+
+int nbmi_frame_keyframe(nbmi_sim *s, float *out_pos, float *out_col) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!out_pos || !out_col) { nbmi::set_error("nbmi_frame_keyframe: null output"); return NBMI_ERR_ARG; }
+    if (int rc = frame_alloc(s)) return rc;
+    float *dp = nullptr;
+    if (int rc = frame_current(s, &dp)) return rc;
+    hipStream_t st = s->stream;
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->frame_prev, dp, (size_t)n * 12, hipMemcpyDeviceToDevice, st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->frame_prev + 3 * n, s->colors, (size_t)n * 12, hipMemcpyDeviceToDevice, st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(out_pos, dp, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(out_col, s->colors, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    s->frame_have_prev = true;
+    if (s->method == NBMI_METHOD_BARNES_HUT) return check_device_error(s);
+    return 0;
+}
+
+int nbmi_frame_delta_i16(nbmi_sim *s, int16_t *out_dpos, int16_t *out_dcol) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!out_dpos || !out_dcol) { nbmi::set_error("nbmi_frame_delta_i16: null output"); return NBMI_ERR_ARG; }
+    if (!s->frame_have_prev) {
+        nbmi::set_error("nbmi_frame_delta_i16: no previous frame on the device (call nbmi_frame_keyframe or "
+                        "nbmi_frame_set_previous first)");
+        return NBMI_ERR_ARG;
+    }
+    float *dp = nullptr;
+    if (int rc = frame_current(s, &dp)) return rc;
+    hipStream_t st = s->stream;
+    k_frame_delta<<<nblocks(3 * n), kBlock, 0, st>>>(dp, s->frame_prev, 3 * n, s->frame_q);
+    k_frame_delta<<<nblocks(3 * n), kBlock, 0, st>>>(s->colors, s->frame_prev + 3 * n, 3 * n, s->frame_q + 3 * n);
+    NBMI_HIP_CHECK(hipGetLastError());
+    NBMI_HIP_CHECK(hipMemcpyAsync(out_dpos, s->frame_q, (size_t)n * 6, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(out_dcol, s->frame_q + 3 * n, (size_t)n * 6, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (s->method == NBMI_METHOD_BARNES_HUT) return check_device_error(s);
+    return 0;
+}
+
+int nbmi_frame_set_previous(nbmi_sim *s, const float *pos, const float *col) {
+    if (int rc = check_handle(s)) return rc;
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    if (!pos || !col) { nbmi::set_error("nbmi_frame_set_previous: null input"); return NBMI_ERR_ARG; }
+    if (int rc = frame_alloc(s)) return rc;
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->frame_prev, pos, (size_t)n * 12, hipMemcpyHostToDevice, s->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->frame_prev + 3 * n, col, (size_t)n * 12, hipMemcpyHostToDevice, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->frame_have_prev = true;
     return 0;
 }
 

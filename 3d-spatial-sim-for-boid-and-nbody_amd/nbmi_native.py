@@ -58,6 +58,9 @@ PROTOTYPES = {
     "nbmi_visible_points": (C.c_int, [_vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),
     "nbmi_set_exchange_sync": (C.c_int, [_vp, C.c_int]),
     "nbmi_stream": (_vp, [_vp]),
+    "nbmi_frame_keyframe": (C.c_int, [_vp, _vp, _vp]),
+    "nbmi_frame_delta_i16": (C.c_int, [_vp, _vp, _vp]),
+    "nbmi_frame_set_previous": (C.c_int, [_vp, _vp, _vp]),
     "nbmi_debug_sort_pairs": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bdmi_create": (_vp, [_i64, _vp, _vp, _vp, _vp, C.c_int]),
     "bdmi_destroy": (None, [_vp]),

@@ -196,6 +196,25 @@ class _HIPSimulation:
         k = int(cnt.value)
         return p[:k], c[:k]
 
+    # frame codec on the device (tools/record.py: format-1 / format-2 payloads of a .zstd frame)
+    def frame_keyframe(self):
+        """(positions f32 (N,3), colours f32 (N,3)); they become the device's previous decoded frame."""
+        p, c = np.empty((self.n, 3), dtype=np.float32), np.empty((self.n, 3), dtype=np.float32)
+        _nat.check(self._lib.nbmi_frame_keyframe(self._h, _nat.ptr(p), _nat.ptr(c)), "nbmi_frame_keyframe")
+        return p, c
+
+    def frame_delta(self):
+        """(int16 (N,3) position deltas, int16 (N,3) colour deltas) = int16((cur - prev) * 1000) against the
+        previous DECODED frame kept on the device (reference tools/record.py:254-262), 12 B/body over PCIe."""
+        dp, dc = np.empty((self.n, 3), dtype=np.int16), np.empty((self.n, 3), dtype=np.int16)
+        _nat.check(self._lib.nbmi_frame_delta_i16(self._h, _nat.ptr(dp), _nat.ptr(dc)), "nbmi_frame_delta_i16")
+        return dp, dc
+
+    def frame_set_previous(self, positions, colors):
+        p = np.ascontiguousarray(positions, dtype=np.float32)
+        c = np.ascontiguousarray(colors, dtype=np.float32)
+        _nat.check(self._lib.nbmi_frame_set_previous(self._h, _nat.ptr(p), _nat.ptr(c)), "nbmi_frame_set_previous")
+
     # multi-GPU row exchange (device pointers; see nbody/sharded.py)
     def set_shard(self, begin, end):
         _nat.check(self._lib.nbmi_set_shard(self._h, int(begin), int(end)), "nbmi_set_shard")

@@ -9,8 +9,11 @@ On-disk contract kept so the reference's playback can read the output (SURVEY 8b
   state_%04d.npz   = positions, velocities every 50 frames, previous one deleted   (:867-876)
                      (+ `masses`, a superset key: the reference loses masses on resume [quirk])
 The interactive menus, progress bars and the background compressor thread are UX and are not
-reproduced; ``compress_recording`` converts finished .npz frames to .zstd in batches of 50 with
-the same delta chaining.  zstd comes from the system libzstd through ctypes (python-zstandard is
+reproduced; ``compress_recording`` converts finished .npz frames to .zstd with the same delta
+chaining, and ``record(config with "zstd": True)`` writes .zstd frames directly: the int16 delta
+payload is quantised ON THE DEVICE against the previous decoded frame kept in HBM (12 instead of
+24 bytes per body over PCIe), zstd runs on the host.  ``extend_recording`` is the reference's
+``--extend`` (:1156-1199); Ctrl-C leaves a state checkpoint like the reference (:916-935).  zstd comes from the system libzstd through ctypes (python-zstandard is
 not installed in this image); without it the .zstd functions raise and raw .npz still works.
 """
 import ctypes as C
@@ -131,16 +134,18 @@ def delta_quantize(cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
         return ((cur - prev) * 1000).astype(np.int16)
 
 
+def pack_container(fmt: int, pos_data: bytes, col_data: bytes) -> bytes:
+    """format byte + u32 length + zstd(positions payload) + u32 length + zstd(colours payload) (reference :264-279)."""
+    pc, cc = zstd_compress(pos_data), zstd_compress(col_data)
+    return struct.pack("B", fmt) + struct.pack("I", len(pc)) + pc + struct.pack("I", len(cc)) + cc
+
+
 def compress_frame(positions, colors, prev_positions=None, prev_colors=None) -> bytes:
     use_delta = prev_positions is not None and prev_colors is not None
     if use_delta:
-        pos_data = delta_quantize(positions, prev_positions).tobytes()
-        col_data = delta_quantize(colors, prev_colors).tobytes()
-    else:
-        pos_data = positions.astype(np.float32).tobytes()
-        col_data = colors.astype(np.float32).tobytes()
-    pc, cc = zstd_compress(pos_data), zstd_compress(col_data)
-    return struct.pack("B", 2 if use_delta else 1) + struct.pack("I", len(pc)) + pc + struct.pack("I", len(cc)) + cc
+        return pack_container(2, delta_quantize(positions, prev_positions).tobytes(),
+                              delta_quantize(colors, prev_colors).tobytes())
+    return pack_container(1, positions.astype(np.float32).tobytes(), colors.astype(np.float32).tobytes())
 
 
 def _split_container(data: bytes):
@@ -295,19 +300,68 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
     if gpu_sim is None:
         raise RuntimeError("[Record] create_gpu_simulation returned None")
     say(f"[Record] GPU acceleration: {backend.value} - {info}")
+    direct_zstd = bool(config.get("zstd"))  # extra config key: write .zstd frames, delta payload quantised on the device
+    if direct_zstd and start_frame > 0:
+        # the delta chain continues from what a reader reconstructs for the last frame on disk
+        gpu_sim.frame_set_previous(*load_frame(rec_dir, start_frame - 1))
     t0 = time.time()
-    for frame in range(start_frame, total_frames):
-        gpu_sim.step_many(dt, substeps)
+
+    def write_frame(frame):
         gpu_sim.compute_colors(15.0)
-        positions = gpu_sim.get_positions()
-        colors = gpu_sim.get_colors()
-        save_frame(rec_dir, frame, positions, colors)
-        if (frame + 1) % STATE_EVERY == 0:
-            np.savez(rec_dir / f"state_{frame:04d}.npz", positions=gpu_sim.get_positions_f64(),
-                     velocities=gpu_sim.get_velocities(), masses=masses)
-            old = rec_dir / f"state_{frame - STATE_EVERY:04d}.npz"
-            if old.exists():
-                old.unlink()
+        if direct_zstd:
+            zf, _ = _frame_paths(rec_dir, frame)
+            if frame == 0:
+                p32, c32 = gpu_sim.frame_keyframe()
+                zf.write_bytes(pack_container(1, p32.tobytes(), c32.tobytes()))
+            else:
+                dp, dc = gpu_sim.frame_delta()
+                zf.write_bytes(pack_container(2, dp.tobytes(), dc.tobytes()))
+        else:
+            save_frame(rec_dir, frame, gpu_sim.get_positions(), gpu_sim.get_colors())
+
+    def write_state(frame, compressed=False):
+        (np.savez_compressed if compressed else np.savez)(
+            rec_dir / f"state_{frame:04d}.npz", positions=gpu_sim.get_positions_f64(),
+            velocities=gpu_sim.get_velocities(), masses=masses)
+
+    frame, stepped = start_frame - 1, False
+    try:
+        for frame in range(start_frame, total_frames):
+            stepped = False
+            gpu_sim.step_many(dt, substeps)
+            stepped = True
+            write_frame(frame)
+            stepped = False
+            if (frame + 1) % STATE_EVERY == 0:
+                write_state(frame)
+                old = rec_dir / f"state_{frame - STATE_EVERY:04d}.npz"
+                if old.exists():
+                    old.unlink()
+    except KeyboardInterrupt:
+        # reference :916-935: "Paused at frame N" + a state file so that --resume continues from there.  The
+        # device may be one frame ahead of the disk: finish that frame first, then checkpoint it.
+        if stepped:
+            write_frame(frame)
+        last = frame if (stepped or frame >= start_frame and _frame_paths(rec_dir, frame)[0].exists()
+                         or _frame_paths(rec_dir, frame)[1].exists()) else frame - 1
+        if last >= 0:
+            write_state(last, compressed=True)
+        say(f"\n[Record] Paused at frame {last}; resume with record(config, resume=True)")
+        gpu_sim.close()
+        raise
     say(f"[Record] {total_frames - start_frame} frames in {time.time() - t0:.2f}s -> {rec_dir}")
     gpu_sim.close()
     return rec_dir
+
+
+def extend_recording(session_name: str, extra_frames: int, root: Path = None, quiet: bool = True):
+    """The reference's ``--extend N session`` (:1156-1199): total_frames += N in metadata.json, then resume."""
+    rec_dir = get_recording_dir(session_name, root)
+    if not (rec_dir / "metadata.json").exists():
+        raise FileNotFoundError(f"[Record] No recording found: {session_name}")
+    config = load_metadata(rec_dir)
+    config["total_frames"] = int(config["total_frames"]) + int(extra_frames)
+    with open(rec_dir / "metadata.json", "w") as f:
+        json.dump(config, f, indent=2)
+    config["session_name"] = session_name
+    return record(config, resume=True, root=root, quiet=quiet)

@@ -197,6 +197,20 @@ int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 
+/* Frame codec on the device (tools/record.py:231-326).  A recording's .zstd frame holds either
+ * absolute float32 positions + colours (format 1) or int16((cur - prev) * 1000) against the previous DECODED
+ * frame (format 2, :254-262, decoder :313-322; lossy, wraps beyond +-32.767 like the reference's cast).  The
+ * previous decoded frame stays in HBM, the quantisation runs on the device, and a delta frame costs 12 bytes per
+ * body over PCIe instead of 24; zstd itself stays on the host.
+ *   nbmi_frame_keyframe      current positions (as nbmi_get_positions_f32) and colours (of the last
+ *                            nbmi_compute_colors), float32 (N,3) each; they become the previous frame
+ *   nbmi_frame_delta_i16     int16 (N,3) position and colour deltas against the previous decoded frame, which is
+ *                            advanced to prev + int16 / 1000 (what load_frame() will reconstruct)
+ *   nbmi_frame_set_previous  restore the previous decoded frame after a resume (decoded by the host codec) */
+int nbmi_frame_keyframe(nbmi_sim *sim, float *out_positions_xyz, float *out_colors_rgb);
+int nbmi_frame_delta_i16(nbmi_sim *sim, int16_t *out_dpos, int16_t *out_dcol);
+int nbmi_frame_set_previous(nbmi_sim *sim, const float *positions_xyz, const float *colors_rgb);
+
 /* Test / measurement hook for the device sort behind the octree build ("Morton-code octree build via
  * device radix sort"; it replaces np.argsort of boids/flock.py:618 as well): sorts n (key, value) pairs
  * given as HOST arrays by the low `bits` bits of the key (key_bytes 4 or 8), stable.  impl 0 = the

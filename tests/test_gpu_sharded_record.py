@@ -289,3 +289,87 @@ def test_record_writes_reference_format_and_resumes(gpu, tmp_path, oracle):
     assert rec.compress_recording(d) == 60
     q, _ = rec.load_frame(d, 59)
     assert np.abs(q - p).max() < 0.06  # int16 millis quantisation accumulates over the chain
+
+
+def test_device_frame_codec_is_the_host_codec_bit_for_bit(gpu):
+    """int16((cur - prev) * 1000) quantised on the device against the previous DECODED frame
+    (reference tools/record.py:254-262, decoder :313-322) equals tools.record.delta_quantize on the same arrays,
+    the wrap-around beyond +-32.767 included; only 12 B per body cross PCIe."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from tools import record as rec
+    g = golden("tree_galaxy_2048")
+    sim = HIPBarnesHutSimulation(g["pos"], g["vel"], g["mass"], float(g["G"]), float(g["eps"]), 1.0, 0.5)
+    sim.compute_colors(15.0)
+    with pytest.raises(RuntimeError, match="no previous frame"):
+        sim.frame_delta()
+    prev_p, prev_c = sim.frame_keyframe()
+    assert np.array_equal(prev_p, sim.get_positions()) and np.array_equal(prev_c, sim.get_colors())
+    for k in range(6):
+        if k == 3:  # a jump of > 32.767 for some bodies: the int16 cast wraps, on the device as on the host
+            x, v = sim.get_positions_f64(), sim.get_velocities()
+            x[::7] += [40.0, -70.0, 33.0]
+            sim.set_state(x, v)
+        sim.step_many(0.1, 2)
+        sim.compute_colors(15.0)
+        dp, dc = sim.frame_delta()
+        cur_p, cur_c = sim.get_positions(), sim.get_colors()
+        assert np.array_equal(dp, rec.delta_quantize(cur_p, prev_p)), k
+        assert np.array_equal(dc, rec.delta_quantize(cur_c, prev_c)), k
+        if k == 3:
+            assert (np.abs((cur_p - prev_p) * 1000) > 32767).any()
+        # the decoder's reconstruction is the next frame's reference, on both sides
+        prev_p = prev_p + dp.astype(np.float32) / 1000.0
+        prev_c = prev_c + dc.astype(np.float32) / 1000.0
+    sim.close()
+
+
+def test_record_direct_zstd_extend_and_interrupt(gpu, tmp_path, monkeypatch):
+    """record() with "zstd": True writes .zstd frames whose delta payload comes from the device; the files are
+    byte-identical to compressing the raw frames on the host.  extend_recording = the reference's --extend
+    (:1156-1199); Ctrl-C leaves a state checkpoint to resume from (:916-935)."""
+    from tools import record as rec
+    from tools.presets import get_preset_config
+    try:
+        rec._load_zstd()
+    except RuntimeError:
+        pytest.skip("no libzstd")
+    cfg = get_preset_config("quick_galaxy")
+    cfg.update(num_bodies=2000, theta=0.5, total_frames=12, substeps=2)
+    raw = rec.record(dict(cfg, session_name="t_raw"), root=tmp_path, quiet=True, seed=5)
+    z = rec.record(dict(cfg, session_name="t_z", zstd=True), root=tmp_path, quiet=True, seed=5)
+    assert rec.get_completed_frames(z) == 12 and (z / "frame_0011.zstd").exists() and not list(z.glob("*.npz"))
+    assert rec.compress_recording(raw) == 12
+    for k in range(12):
+        assert (z / f"frame_{k:04d}.zstd").read_bytes() == (raw / f"frame_{k:04d}.zstd").read_bytes(), k
+    p11, _ = rec.load_frame(z, 11)
+    # --extend: 12 -> 60 frames; no state file yet, so the run restarts from frame 0 like the reference does
+    d = rec.extend_recording("t_z", 48, root=tmp_path)
+    assert d == z and rec.load_metadata(z)["total_frames"] == 60 and rec.get_completed_frames(z) == 60
+    assert np.array_equal(rec.load_frame(z, 11)[0], p11) and (z / "state_0049.npz").exists()
+    # resume in direct-zstd mode continues the delta chain from the decoded last frame on disk
+    before = [(z / f"frame_{k:04d}.zstd").read_bytes() for k in range(50, 60)]
+    for k in range(50, 60):
+        (z / f"frame_{k:04d}.zstd").unlink()
+    rec.record(dict(rec.load_metadata(z), session_name="t_z"), resume=True, root=tmp_path, quiet=True)
+    assert [(z / f"frame_{k:04d}.zstd").read_bytes() for k in range(50, 60)] == before
+    # Ctrl-C in the middle of a run: the frame in flight is finished, a state file is left, resume completes
+    calls = {"n": 0}
+    real = rec.save_frame
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        real(*a, **k)
+        if calls["n"] == 7:
+            raise KeyboardInterrupt
+
+    monkeypatch.setattr(rec, "save_frame", flaky)
+    with pytest.raises(KeyboardInterrupt):
+        rec.record(dict(cfg, session_name="t_int"), root=tmp_path, quiet=True, seed=5)
+    monkeypatch.setattr(rec, "save_frame", real)
+    ti = tmp_path / "recordings" / "t_int"
+    assert rec.get_completed_frames(ti) == 7 and (ti / "state_0006.npz").exists()
+    rec.record(dict(cfg, session_name="t_int"), resume=True, root=tmp_path, quiet=True)
+    assert rec.get_completed_frames(ti) == 12
+    a, _ = rec.load_frame(ti, 11)
+    b, _ = rec.load_frame(raw, 11)
+    assert np.abs(a - b).max() < 0.06  # raw frames vs the (lossy) compressed copy of the uninterrupted run
