@@ -274,6 +274,13 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
                 say(f"[Record] Resuming from frame {start_frame}")
     device_ic = bool(config.get("device_ic")) and positions is None
     if positions is None:
+        # `seed` is a superset key of metadata.json: a resume / extend that finds no state checkpoint starts
+        # over from frame 0 (as the reference does) and must then draw the SAME bodies (the reference, unseeded,
+        # silently continues a recording with a different system)
+        if seed is None:
+            seed = config.get("seed")
+        else:
+            config = dict(config, seed=int(seed))
         if not device_ic:
             if seed is not None:
                 np.random.seed(seed)
