@@ -109,3 +109,61 @@ void walk_sim(const double *pos, const int64_t *order, int64_t n, int gs, int T,
     (void)cmp_desc;
     out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5; out[6] = o6; out[7] = o7;
 }
+
+/* Composition of a lock-step group walk: out[0] visits on cells, [1] visits on leaves, [2] visits on leaves whose
+ * parent has only leaves as children ("twig"), [3] lane-visits on cells, [4] on leaves, [5] on twig leaves,
+ * [6] twig openings (group visits of a twig that some member opens), [7] cells that are twigs among visited cells */
+void walk_mix(const double *pos, const int64_t *order, int64_t n, int gs, const double *half, const double *com,
+              const int32_t *children, const uint8_t *is_leaf, double theta, double softening, int64_t *out) {
+    const double eps2 = softening * softening;
+    int64_t ngroups = n / gs;
+    int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma omp parallel
+    {
+        int64_t q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 8)
+        for (int64_t g = 0; g < ngroups; g++) {
+            int64_t lo = g * gs;
+            int cap = 8192, sp = 0;
+            int32_t *sn = (int32_t *)malloc(sizeof(int32_t) * cap);
+            mask_t *sm = (mask_t *)malloc(sizeof(mask_t) * cap);
+            uint8_t *st = (uint8_t *)malloc(cap);  /* parent was a twig */
+            sn[0] = 0; sm[0] = (((mask_t)1) << gs) - 1; st[0] = 0; sp = 1;
+            while (sp > 0) {
+                sp--;
+                int32_t node = sn[sp];
+                mask_t mask = sm[sp];
+                int under_twig = st[sp];
+                int a = 0;
+                mask_t open = 0;
+                for (int l = 0; l < gs; l++) {
+                    if (!((mask >> l) & 1)) continue;
+                    a++;
+                    if (is_leaf[node]) continue;
+                    int64_t i = order[lo + l];
+                    double dx = com[3 * node] - pos[3 * i], dy = com[3 * node + 1] - pos[3 * i + 1], dz = com[3 * node + 2] - pos[3 * i + 2];
+                    double dist = sqrt(dx * dx + dy * dy + dz * dz + eps2);
+                    if (!(half[node] * 2.0 / dist < theta)) open |= ((mask_t)1) << l;
+                }
+                if (is_leaf[node]) { q[1]++; q[4] += a; if (under_twig) { q[2]++; q[5] += a; } continue; }
+                q[0]++; q[3] += a;
+                int twig = 1;
+                for (int c = 0; c < 8; c++) { int32_t ch = children[8 * (int64_t)node + c]; if (ch >= 0 && !is_leaf[ch]) twig = 0; }
+                q[7] += twig;
+                if (!open) continue;
+                q[6] += twig;
+                for (int c = 0; c < 8; c++) {
+                    int32_t ch = children[8 * (int64_t)node + c];
+                    if (ch >= 0) {
+                        if (sp == cap) { cap *= 2; sn = realloc(sn, sizeof(int32_t) * cap); sm = realloc(sm, sizeof(mask_t) * cap); st = realloc(st, cap); }
+                        sn[sp] = ch; sm[sp] = open; st[sp] = (uint8_t)twig; sp++;
+                    }
+                }
+            }
+            free(sn); free(sm); free(st);
+        }
+#pragma omp critical
+        for (int k = 0; k < 8; k++) o[k] += q[k];
+    }
+    for (int k = 0; k < 8; k++) out[k] = o[k];
+}
