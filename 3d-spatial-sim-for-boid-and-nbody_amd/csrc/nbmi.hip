@@ -1519,9 +1519,13 @@ __global__ void k_super_boxes(const double *__restrict__ boxes, int nsupers, dou
     for (int c = 0; c < 6; c++) supers[6 * sidx + c] = v[c];
 }
 
-// ---- plain int32 exclusive scan (three phases, like the moment scan) ---------------------------
-__global__ __launch_bounds__(kBlock) void k_iscan_reduce(const int32_t *__restrict__ in, int64_t n, int32_t *__restrict__ tile_sum) {
+// ---- plain int32 exclusive scan (three phases, like the moment scan); blockIdx.y selects one of several
+// equally long arrays `stride` elements apart (one per destination rank) ---------------------------------
+__global__ __launch_bounds__(kBlock) void k_iscan_reduce(const int32_t *__restrict__ in, int64_t n, int64_t stride,
+                                                         int32_t *__restrict__ tile_sum, int64_t tstride) {
     __shared__ int red[kBlock / 64];
+    in += (int64_t)blockIdx.y * stride;
+    tile_sum += (int64_t)blockIdx.y * tstride;
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
     int acc = 0;
 #pragma unroll
@@ -1539,9 +1543,10 @@ __global__ __launch_bounds__(kBlock) void k_iscan_reduce(const int32_t *__restri
         tile_sum[blockIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_iscan_tiles(int32_t *__restrict__ tile_sum, int64_t ntiles) {
+__global__ __launch_bounds__(kBlock) void k_iscan_tiles(int32_t *__restrict__ tile_sum, int64_t ntiles, int64_t tstride) {
     __shared__ int wsum[kBlock / 64];
     __shared__ int carry_s;
+    tile_sum += (int64_t)blockIdx.y * tstride;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (int64_t base = 0; base < ntiles; base += kBlock) {
@@ -1565,9 +1570,13 @@ __global__ __launch_bounds__(kBlock) void k_iscan_tiles(int32_t *__restrict__ ti
     }
 }
 // out[i] = sum of in[0..i); entry n receives the total
-__global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restrict__ in, int64_t n, const int32_t *__restrict__ tile_off,
+__global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restrict__ in, int64_t n, int64_t stride,
+                                                        const int32_t *__restrict__ tile_off, int64_t tstride,
                                                         int32_t *__restrict__ out) {
     __shared__ int wsum[kBlock / 64];
+    in += (int64_t)blockIdx.y * stride;
+    out += (int64_t)blockIdx.y * stride;
+    tile_off += (int64_t)blockIdx.y * tstride;
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int v[kScanItems], sum = 0;
 #pragma unroll
@@ -1603,61 +1612,104 @@ __device__ __forceinline__ bool box_may_open(const double *__restrict__ b, const
     const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
     return (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9) <= thr;  // some point of the box may fail "size / dist < theta"
 }
+// one pass over the own tree decides for EVERY destination rank: diff row j marks the pre-order ranges rank j
+// does not need.  Three-level test per destination: the union box of the rank, its super boxes, its boxes.
 __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
                                                      int64_t num_nodes, const double *__restrict__ boxes,
-                                                     const double *__restrict__ supers, int world, int me,
-                                                     double theta, double eps2, int32_t *__restrict__ diff) {
+                                                     const double *__restrict__ supers, const double *__restrict__ rankbox,
+                                                     int world, int me, double theta, double eps2,
+                                                     int32_t *__restrict__ diff, int64_t stride) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_nodes) return;
     const Node nd = nodes[i];
     if (__float_as_int(nd.s2t) == 0) return;  // a leaf: nothing below it
     const Node64 c = n64[i];
     const double size = c.hs * 2.0;
-    bool needed = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
-    const double thr = needed ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
-    for (int sb = 0; sb < world * kSupersPerRank && !needed; sb++) {
-        if (sb / kSupersPerRank == me) continue;
-        if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
-        for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
-    }
-    if (!needed) {
-        const int64_t nx = nd.next_off / kNodeBytes;
-        if (nx > i + 1) {
-            atomicAdd(&diff[i + 1], 1);
-            atomicAdd(&diff[nx], -1);
+    const bool all = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
+    const double thr = all ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
+    const int64_t nx = nd.next_off / kNodeBytes;
+    if (nx <= i + 1) return;
+    for (int j = 0; j < world; j++) {
+        if (j == me) continue;
+        bool needed = all;
+        if (!needed && box_may_open(rankbox + 6 * j, c, eps2, thr)) {
+            for (int sb = j * kSupersPerRank; sb < (j + 1) * kSupersPerRank && !needed; sb++) {
+                if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
+                for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
+            }
+        }
+        if (!needed) {
+            int32_t *d = diff + (int64_t)j * stride;
+            atomicAdd(&d[i + 1], 1);
+            atomicAdd(&d[nx], -1);
         }
     }
 }
 __global__ __launch_bounds__(kBlock) void k_let_keep(const int32_t *__restrict__ diff, const int32_t *__restrict__ diff_ex,
-                                                     int64_t num_nodes, int32_t *__restrict__ keep) {
+                                                     int64_t num_nodes, int64_t stride, int32_t *__restrict__ keep) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < num_nodes) keep[i] = (diff_ex[i] + diff[i]) == 0 ? 1 : 0;
+    const int64_t o = (int64_t)blockIdx.y * stride;
+    if (i < num_nodes) keep[o + i] = (diff_ex[o + i] + diff[o + i]) == 0 ? 1 : 0;
 }
-// kept nodes move to their new index; links are re-based to the compacted numbering (a kept node's
-// successor is always kept: it hangs off one of the node's own ancestors)
+// kept nodes move to their new index in the destination's segment; links are re-based to the compacted
+// numbering (a kept node's successor is always kept: it hangs off one of the node's own ancestors).  A row of
+// the exchange buffer is 56 bytes: the 24-byte walk record, then its float64 twin.
+constexpr int kLetRow = 56;
 __global__ __launch_bounds__(kBlock) void k_let_compact(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
                                                         const int32_t *__restrict__ keep, const int32_t *__restrict__ newidx,
-                                                        int64_t num_nodes, int64_t capacity, Node *__restrict__ out_nodes,
-                                                        Node64 *__restrict__ out_n64) {
+                                                        int64_t num_nodes, int64_t stride, int64_t capacity, int me,
+                                                        const int64_t *__restrict__ seg_off, char *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_nodes || !keep[i]) return;
-    const int64_t j = newidx[i];
-    if (j >= capacity) return;  // reported through the count
+    const int j = blockIdx.y;
+    if (j == me || i >= num_nodes) return;
+    const int64_t o = (int64_t)j * stride;
+    if (!keep[o + i]) return;
+    const int64_t k = seg_off[j] + newidx[o + i];
+    if (k >= capacity) return;  // reported through the counts
     Node nd = nodes[i];
     const int64_t nx = nd.next_off / kNodeBytes;
-    nd.next_off = (unsigned)newidx[nx] * kNodeBytes;
-    out_nodes[j] = nd;
-    out_n64[j] = n64[i];
+    nd.next_off = (unsigned)newidx[o + nx] * kNodeBytes;
+    char *row = out + k * kLetRow;
+    *reinterpret_cast<Node *>(row) = nd;
+    const Node64 c = n64[i];
+    double *d = reinterpret_cast<double *>(row + kNodeBytes);
+    d[0] = c.cx; d[1] = c.cy; d[2] = c.cz; d[3] = c.hs;
+}
+// rows per destination and where each destination's segment starts in the (packed) send buffer
+__global__ void k_let_counts(const int32_t *__restrict__ newidx, int64_t num_nodes, int64_t stride, int world, int me,
+                             int64_t *__restrict__ counts /* [world] counts, then [world] offsets */) {
+    if (threadIdx.x != 0) return;
+    int64_t off = 0;
+    for (int j = 0; j < world; j++) {
+        const int64_t c = j == me ? 0 : newidx[(int64_t)j * stride + num_nodes];
+        counts[j] = c;
+        counts[world + j] = off;
+        off += c;
+    }
+}
+// union box of each rank's super boxes
+__global__ void k_rank_boxes(const double *__restrict__ supers, int world, double *__restrict__ rankbox) {
+    const int j = threadIdx.x;
+    if (j >= world) return;
+    double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < kSupersPerRank; k++) {
+        const double *b = supers + 6 * (j * kSupersPerRank + k);
+        if (!(b[0] <= b[3])) continue;
+        for (int c = 0; c < 3; c++) { v[c] = fmin(v[c], b[c]); v[3 + c] = fmax(v[3 + c], b[3 + c]); }
+    }
+    for (int c = 0; c < 6; c++) rankbox[6 * j + c] = v[c];
 }
 // a received tree goes behind the trees already in the walk array: links shift by the base
-__global__ __launch_bounds__(kBlock) void k_let_append(const Node *__restrict__ src, const Node64 *__restrict__ src64, int64_t count,
-                                                       int64_t base, Node *__restrict__ nodes, Node64 *__restrict__ n64) {
+__global__ __launch_bounds__(kBlock) void k_let_append(const char *__restrict__ src, int64_t count, int64_t base,
+                                                       Node *__restrict__ nodes, Node64 *__restrict__ n64) {
     const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
-    Node nd = src[k];
+    const char *row = src + k * kLetRow;
+    Node nd = *reinterpret_cast<const Node *>(row);
     nd.next_off += (unsigned)base * kNodeBytes;
     nodes[base + k] = nd;
-    n64[base + k] = src64[k];
+    const double *d = reinterpret_cast<const double *>(row + kNodeBytes);
+    n64[base + k] = Node64{d[0], d[1], d[2], d[3]};
 }
 __global__ void k_let_finish(Node *__restrict__ nodes, int64_t total, TreeInfo *info) {
     Node sn;
@@ -1723,7 +1775,8 @@ struct nbmi_sim {
     uint32_t *let_dest = nullptr, *let_dest_s = nullptr, *let_order = nullptr;
     int64_t *let_counts = nullptr;
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
-    double *let_supers = nullptr;
+    double *let_supers = nullptr, *let_rankbox = nullptr;
+    int64_t let_stride = 0, let_tile_stride = 0;  // rows between two destinations' work arrays
     // frame codec: previous decoded frame (positions then colours, float32, caller's order) and the int16 payload
     float *frame_prev = nullptr;
     int16_t *frame_q = nullptr;
@@ -2486,11 +2539,14 @@ int owner_check(nbmi_sim *s, const char *what) {
     }
     return 0;
 }
-int enqueue_iscan(nbmi_sim *s, const int32_t *in, int64_t n, int32_t *out) {  // out has n + 1 entries
+// `batch` arrays of n (+1 output) entries, `stride` apart
+int enqueue_iscan(nbmi_sim *s, const int32_t *in, int64_t n, int32_t *out, int batch = 1, int64_t stride = 0) {
     const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;
-    k_iscan_reduce<<<(int)ntiles, kBlock, 0, s->stream>>>(in, n, s->let_tiles);
-    k_iscan_tiles<<<1, kBlock, 0, s->stream>>>(s->let_tiles, ntiles);
-    k_iscan_apply<<<(int)ntiles, kBlock, 0, s->stream>>>(in, n, s->let_tiles, out);
+    const int64_t tstride = s->let_tile_stride;
+    const dim3 grid((unsigned)ntiles, (unsigned)batch);
+    k_iscan_reduce<<<grid, kBlock, 0, s->stream>>>(in, n, stride, s->let_tiles, tstride);
+    k_iscan_tiles<<<dim3(1, (unsigned)batch), kBlock, 0, s->stream>>>(s->let_tiles, ntiles, tstride);
+    k_iscan_apply<<<grid, kBlock, 0, s->stream>>>(in, n, stride, s->let_tiles, tstride, out);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2517,16 +2573,20 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
     s->owner = true; s->world = world; s->rank = rank;
     s->let_capacity = let_capacity;
-    s->node_extra = let_capacity * (world - 1);
+    s->node_extra = world > 1 ? let_capacity : 0;
     read_env_knobs(s);
     int rc = create_impl(s, pos, vel, mass);
     if (rc == 0) {
-        const int64_t c = s->cap, rows = s->node_capacity + 2;
+        const int64_t c = s->cap;
+        // per-destination work arrays over the OWN tree's rows (diff / scan / keep), one row set per rank
+        s->let_stride = s->own_node_rows + 8;
+        s->let_tile_stride = s->let_stride / kScanTile + 4;
+        const size_t all = (size_t)s->let_stride * world;
         if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) || dev_alloc(s, &s->let_dest_s, c) ||
-            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, kMaxWorld) ||
-            dev_alloc(s, &s->let_diff, rows) || dev_alloc(s, &s->let_scan, rows) || dev_alloc(s, &s->let_keep, rows) ||
-            dev_alloc(s, &s->let_tiles, rows / kScanTile + 4) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
-            dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld))
+            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, 2 * kMaxWorld) ||
+            dev_alloc(s, &s->let_diff, all) || dev_alloc(s, &s->let_scan, all) || dev_alloc(s, &s->let_keep, all) ||
+            dev_alloc(s, &s->let_tiles, (size_t)s->let_tile_stride * world) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
+            dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
             rc = -2;
     }
     if (rc == 0 && n > 0) {  // global ids instead of the row numbers k_split_state wrote
@@ -2651,65 +2711,63 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, cons
     return 0;
 }
 
-int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int64_t *count) {
+int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int64_t *counts /* world, host */) {
     if (int rc = owner_check(s, "nbmi_owner_export_let")) return rc;
-    if (!dev_boxes || !dev_let || !count) { nbmi::set_error("nbmi_owner_export_let: null buffer"); return NBMI_ERR_ARG; }
-    *count = 0;
-    if (s->n == 0) return 0;
+    if (!dev_boxes || !dev_let || !counts) { nbmi::set_error("nbmi_owner_export_let: null buffer"); return NBMI_ERR_ARG; }
+    for (int j = 0; j < s->world; j++) counts[j] = 0;
+    if (s->n == 0 || s->world == 1) return 0;
     hipStream_t st = s->stream;
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
     NBMI_HIP_CHECK(hipStreamSynchronize(st));
     if (h.error) return check_device_error(s);
-    const int64_t nn = h.num_nodes;
-    NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)(nn + 1) * 4, st));
-    k_super_boxes<<<(s->world * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, s->world * kSupersPerRank,
-                                                                       s->let_supers);
-    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->world, s->rank,
-                                              s->theta, s->softening * s->softening, s->let_diff);
-    if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan)) return rc;
-    k_let_keep<<<nblocks(nn), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, s->let_keep);
-    if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan)) return rc;
-    Node *out_nodes = (Node *)dev_let;
-    Node64 *out_n64 = (Node64 *)((char *)dev_let + (size_t)s->let_capacity * kNodeBytes);
-    k_let_compact<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, s->let_capacity, out_nodes,
-                                                 out_n64);
+    const int64_t nn = h.num_nodes, stride = s->let_stride;
+    const int W = s->world;
+    NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)stride * W * 4, st));
+    k_super_boxes<<<(W * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, W * kSupersPerRank, s->let_supers);
+    k_rank_boxes<<<1, kMaxWorld, 0, st>>>(s->let_supers, W, s->let_rankbox);
+    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_rankbox, W,
+                                              s->rank, s->theta, s->softening * s->softening, s->let_diff, stride);
+    if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
+    k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep);
+    if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan, W, stride)) return rc;
+    k_let_counts<<<1, 64, 0, st>>>(s->let_scan, nn, stride, W, s->rank, s->let_counts);
+    k_let_compact<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, stride,
+                                                                            s->let_capacity, s->rank, s->let_counts + W, (char *)dev_let);
     NBMI_HIP_CHECK(hipGetLastError());
-    int32_t total = 0;
-    NBMI_HIP_CHECK(hipMemcpyAsync(&total, s->let_scan + nn, 4, hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
     NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    int64_t total = 0;
+    for (int j = 0; j < W; j++) total += counts[j];
     if (total > s->let_capacity) {
-        nbmi::set_error("nbmi_owner_export_let: the locally essential tree has %d nodes, more than the %lld rows reserved",
-                        total, (long long)s->let_capacity);
+        nbmi::set_error("nbmi_owner_export_let: the trees for the other ranks have %lld nodes, more than the %lld rows reserved",
+                        (long long)total, (long long)s->let_capacity);
         return NBMI_ERR_CAPACITY;
     }
-    *count = total;
     return 0;
 }
 
-int nbmi_owner_step(nbmi_sim *s, const void *dev_lets, const int64_t *counts, double dt) {
+int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, double dt) {
     if (int rc = owner_check(s, "nbmi_owner_step")) return rc;
-    if (!counts || (s->world > 1 && !dev_lets)) { nbmi::set_error("nbmi_owner_step: null buffer"); return NBMI_ERR_ARG; }
+    if (!counts || (s->world > 1 && !dev_recv)) { nbmi::set_error("nbmi_owner_step: null buffer"); return NBMI_ERR_ARG; }
     if (s->n == 0) return 0;
     hipStream_t st = s->stream;
     TreeInfo h;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
     NBMI_HIP_CHECK(hipStreamSynchronize(st));
     if (h.error) return check_device_error(s);
-    int64_t total = h.num_nodes;
-    const size_t stride = (size_t)s->let_capacity * (kNodeBytes + sizeof(Node64));
-    for (int j = 0; j < s->world; j++) {
+    int64_t total = h.num_nodes, seen = 0;
+    for (int j = 0; j < s->world; j++) {  // the received trees are packed one after the other, in rank order
         if (j == s->rank || counts[j] <= 0) continue;
-        if (counts[j] > s->let_capacity || total + counts[j] + 1 > s->node_capacity) {
+        if (total + counts[j] + 1 > s->node_capacity) {
             nbmi::set_error("nbmi_owner_step: received trees do not fit (%lld + %lld of %lld rows)", (long long)total,
                             (long long)counts[j], (long long)s->node_capacity);
             return NBMI_ERR_CAPACITY;
         }
-        const char *base = (const char *)dev_lets + stride * j;
-        k_let_append<<<nblocks(counts[j]), kBlock, 0, st>>>((const Node *)base,
-                                                            (const Node64 *)(base + (size_t)s->let_capacity * kNodeBytes),
-                                                            counts[j], total, s->nodes, s->nodes64);
+        k_let_append<<<nblocks(counts[j]), kBlock, 0, st>>>((const char *)dev_recv + seen * kLetRow, counts[j], total, s->nodes,
+                                                            s->nodes64);
         total += counts[j];
+        seen += counts[j];
     }
     k_let_finish<<<1, 1, 0, st>>>(s->nodes, total, s->info);
     NBMI_HIP_CHECK(hipGetLastError());
@@ -2718,7 +2776,6 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_lets, const int64_t *counts, do
     s->tree_valid = false;
     return 0;
 }
-
 
 // ---- frame codec ----------------------------------------------------------------
 namespace {

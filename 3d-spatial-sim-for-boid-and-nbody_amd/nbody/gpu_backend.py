@@ -360,10 +360,11 @@ class HIPOwnerSimulation(HIPBarnesHutSimulation):
                    "nbmi_owner_adopt")
 
     def owner_export_let(self, dev_boxes, dev_let):
-        cnt = C.c_int64(0)
-        _nat.check(self._lib.nbmi_owner_export_let(self._h, int(dev_boxes), int(dev_let), C.addressof(cnt)),
+        """Rows for every destination rank (packed in rank order in `dev_let`); returns the counts."""
+        counts = np.zeros(self.world, dtype=np.int64)
+        _nat.check(self._lib.nbmi_owner_export_let(self._h, int(dev_boxes), int(dev_let), _nat.ptr(counts)),
                    "nbmi_owner_export_let")
-        return int(cnt.value)
+        return counts
 
     def owner_step(self, dev_lets, counts, dt):
         counts = np.ascontiguousarray(counts, dtype=np.int64)

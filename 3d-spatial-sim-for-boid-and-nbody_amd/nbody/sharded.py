@@ -12,9 +12,10 @@ The reference is single-device; this is new design, in two forms:
   of the whole system), keys, all-gather of a few hundred key samples -> splitters at equal quantiles,
   all-to-all-v of the rows that crossed a splitter (body migration: a rank's bodies always form one compact
   key range, so its waves stay compact), local sort + octree of the owned bodies inside the global cube,
-  all-gather of the ranks' bounding boxes, pruning of the own tree against the others' boxes (the
-  reference's opening test at the box's nearest point, conservative by 1e-9), all-gather of the pruned
-  trees (56 B per node: the 24-byte walk record and its float64 twin), walk over own + received trees.
+  all-gather of the ranks' bounding boxes (tight boxes of the cells of each rank's own tree), pruning of
+  the own tree against EACH other rank's boxes (the reference's opening test at the box's nearest point,
+  conservative by 1e-9), all-to-all-v of the pruned trees (56 B per node: the 24-byte walk record and its
+  float64 twin; a rank only receives what its own bodies can open), walk over own + received trees.
   Per-rank sort / build / state no longer grow with the world size; only the received trees do.  Cells
   that straddle rank boundaries appear once per rank (partial cells), so positions agree with the 1-GPU
   run to a stated tolerance instead of bit for bit.
@@ -158,12 +159,13 @@ def create_sharded_simulation(positions, velocities, masses, G, softening, dampi
 
 
 def let_capacities(n_total, world):
-    """(body capacity, rows of one locally essential tree) of a rank: 25 % head room over the equal share
-    (the splitters re-balance every step, so the share only drifts by sampling noise) and, for the tree a
-    rank sends to the others, two thirds of its own ~1.5 n nodes (measured at 1 M bodies per rank: see DESIGN section 6)."""
+    """(body capacity, rows for exchanged trees) of a rank: 25 % head room over the equal share (the splitters
+    re-balance every step, so the share only drifts by sampling noise) and, for the trees a rank sends to / receives
+    from all the others together, as many rows as its own tree has (~1.5 per body; measured at 1 M bodies per
+    rank and 8 ranks: a third of that)."""
     share = (n_total + world - 1) // world
     cap = int(share * 1.25) + 4096
-    let = 0 if world == 1 else int(1.0 * share) + 65536
+    let = 0 if world == 1 else int(1.5 * share) + 65536
     return cap, let
 
 
@@ -204,9 +206,9 @@ class HipLetEngine:
         nbox = 6 * int(self.sim._lib.nbmi_owner_boxes_per_rank())  # several boxes per rank: a key range is not a box
         self.bbox = z(nbox)
         self.boxes = z(world * nbox)
-        let_bytes = let * 56  # 24-byte walk record + 32-byte float64 twin
-        self.let_mine = torch.zeros(max(let_bytes, 8), dtype=torch.uint8, device=self.device)
-        self.let_all = torch.zeros(max(let_bytes, 8) * world, dtype=torch.uint8, device=self.device)
+        # trees travel as 56-byte rows (24-byte walk record + 32-byte float64 twin), one packed segment per rank
+        self.let_send = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
+        self.let_recv = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)  # the fills ran on torch's stream, the library has its own
         self.wire_bytes = 0  # bytes this rank sent in the last step (rows + tree + small collectives)
         self.migrated = 0    # bodies this rank handed to other ranks in the last step
@@ -226,10 +228,10 @@ class HipLetEngine:
         self.sim.owner_adopt(rows.data_ptr(), n_new, self.maxabs.data_ptr(), self.bbox.data_ptr())
 
     def op_export_let(self):
-        return self.sim.owner_export_let(self.boxes.data_ptr(), self.let_mine.data_ptr())
+        return self.sim.owner_export_let(self.boxes.data_ptr(), self.let_send.data_ptr())
 
-    def op_step(self, counts, dt):
-        self.sim.owner_step(self.let_all.data_ptr(), counts, dt)
+    def op_step(self, recv_counts, dt):
+        self.sim.owner_step(self.let_recv.data_ptr(), recv_counts, dt)
 
     def wait(self):
         """A collective issued on torch's stream has finished (the library works on its own stream)."""
@@ -242,9 +244,9 @@ class HipLetEngine:
 
 class LetBarnesHut:
     """step() over `world` ranks in owner mode; see the module docstring.  The engine owns the buffers
-    (maxabs, samples / all_samples, send_rows / recv_rows, bbox / boxes, let_mine / let_all: torch tensors)
+    (maxabs, samples / all_samples, send_rows / recv_rows, bbox / boxes, let_send / let_recv: torch tensors)
     and the six phases op_*; `comm` provides all_reduce_max(t), all_gather(full, mine),
-    all_to_all_counts(np int64[world]) -> np int64[world], all_gather_counts(int) -> np int64[world] and
+    all_to_all_counts(np int64[world]) -> np int64[world] and
     all_to_all_rows(recv, send, recv_counts, send_counts) (default: torch.distributed, DistComm)."""
 
     def __init__(self, engine, rank, world, comm=None):
@@ -287,11 +289,14 @@ class LetBarnesHut:
             if W > 1:
                 self.comm.all_gather(e.boxes, e.bbox)
                 e.wait()
-                mine = e.op_export_let()
-                counts = self.comm.all_gather_counts(mine)
-                self.comm.all_gather(e.let_all, e.let_mine)
+                let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
+                counts = self.comm.all_to_all_counts(let_counts)
+                if int(counts.sum()) > e.let_recv.shape[0]:
+                    raise RuntimeError(f"rank {self.rank}: {int(counts.sum())} received tree rows exceed the "
+                                       f"{e.let_recv.shape[0]} reserved")
+                self.comm.all_to_all_rows(e.let_recv, e.let_send, counts, let_counts)
                 e.wait()
-                wire += e.bbox.numel() * 8 + mine * e.LET_ROW_BYTES
+                wire += e.bbox.numel() * 8 + int(let_counts.sum()) * e.LET_ROW_BYTES
             e.op_step(counts, dt)
             e.let_counts = counts
             e.wire_bytes = wire

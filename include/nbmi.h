@@ -141,7 +141,7 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * rank's key range (rebalanced every step), builds the octree of THOSE bodies inside the GLOBAL root cube
  * (compute_bounds over the whole system, simulation.py:308-317) and walks its own tree plus, behind it in the
  * same node array, the part of every other rank's tree that some body of this rank can open (the other ranks
- * prune their trees against this rank's bounding box with the reference's own opening test, made conservative
+ * prune their trees against this rank's bounding boxes with the reference's own opening test, made conservative
  * by 1e-9).  Per-rank sort / build / memory no longer grow with the number of ranks.  Cells that straddle a
  * rank boundary are seen as one partial cell per rank instead of one whole cell, so positions agree with
  * the single-GPU run to a tolerance (measured 1e-9 relative after 5 steps at 100 k bodies), not bit for bit;
@@ -159,11 +159,13 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *                                                   box <- B = nbmi_owner_boxes_per_rank() bounding boxes (6 doubles
  *                                                   each: lo xyz, hi xyz), one per equal chunk of the key order
  *        all-gather of the boxes                    (world x B x 6 doubles)
- *   nbmi_owner_export_let(h, boxes, let, &count)    prune the own tree against the other ranks' boxes into `let`:
- *                                                   let_capacity rows of 24-byte nodes, then let_capacity 32-byte rows
- *                                                   of their float64 twins; count on the host
- *        all-gather of the counts and of `let`      (world x let_capacity x 56 B, `count` rows of each used)
- *   nbmi_owner_step(h, lets, counts, dt)            append the received trees behind the own one, walk, kick-drift
+ *   nbmi_owner_export_let(h, boxes, let, counts)    prune the own tree against EACH other rank's boxes: counts[j] rows
+ *                                                   for rank j, packed one destination after the other in `let`
+ *                                                   (56-byte rows: the 24-byte walk record + its float64 twin;
+ *                                                   let_capacity rows in all); counts[world] on the host
+ *        all-to-all of the counts, all-to-all-v of the rows
+ *   nbmi_owner_step(h, recv, recv_counts, dt)       append the received trees (packed in rank order, at most
+ *                                                   let_capacity rows) behind the own one, walk, kick-drift
  *
  * Getters of an owner handle return the owned bodies in their current (key) order; nbmi_owner_get_ids gives the
  * global body ids of those rows. */
@@ -178,8 +180,8 @@ int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, 
 int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
                          int64_t *counts_host);
 int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_boxes);
-int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *count_host);
-int nbmi_owner_step(nbmi_sim *sim, const void *dev_lets, const int64_t *counts_host, double dt);
+int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *counts_host);
+int nbmi_owner_step(nbmi_sim *sim, const void *dev_recv_let, const int64_t *recv_counts_host, double dt);
 
 /* Render-side reduction: NBodySimulation._compute_visibility + the gather of
  * draw() on the device (nbody/simulation.py:880-903, 927-928).  Frustum test of

@@ -66,26 +66,30 @@ for W in Ws:
             if rec and e.rank == 0: ph["adopt_sort_build"] += t
             e.migrated = int(sc[e.rank].sum() - sc[e.rank][e.rank])
         boxes = torch.cat([e.bbox for e in E])
-        counts = np.zeros(W, dtype=np.int64)
+        lc = [np.zeros(W, dtype=np.int64) for _ in E]
         if W > 1:
             for e in E:
                 e.boxes.copy_(boxes)
                 c, t = timed(e.op_export_let)
-                counts[e.rank] = c
+                lc[e.rank] = c
                 if rec and e.rank == 0: ph["export_tree"] += t
-            let_all = torch.cat([e.let_mine for e in E])
         for e in E:
-            if W > 1:
-                e.let_all.copy_(let_all)
-            _, t = timed(lambda: (e.op_step(counts, dt), e.sim.sync()))
+            rc = np.array([lc[j][e.rank] for j in range(W)], dtype=np.int64)
+            off = 0
+            for j in range(W):
+                start, c = int(lc[j][:e.rank].sum()), int(rc[j])
+                e.let_recv[off:off + c].copy_(E[j].let_send[start:start + c])
+                off += c
+            e.let_counts = rc
+            _, t = timed(lambda: (e.op_step(rc, dt), e.sim.sync()))
             if rec and e.rank == 0: ph["walk"] += t
     k = steps - 1
     own_nodes = E[0].sim.tree_stats(depth=False)["num_nodes"]
     row = {"world": W, "bodies_per_rank": per, "rank0_ms": {a: round(b / k, 3) for a, b in ph.items()},
            "rank0_ms_total": round(sum(ph.values()) / k, 3), "rank0_owned": E[0].sim.n, "rank0_own_tree_nodes": own_nodes,
-           "tree_rows_received_by_rank0": int(counts.sum() - counts[0]), "tree_rows_sent_by_rank0": int(counts[0]),
+           "tree_rows_received_by_rank0": int(E[0].let_counts.sum()), "tree_rows_sent_by_rank0": int(lc[0].sum()),
            "rows_migrated_from_rank0": E[0].migrated,
-           "bytes_sent_by_rank0": int(counts[0]) * 56 + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
+           "bytes_sent_by_rank0": int(lc[0].sum()) * 56 + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
     if W == Ws[0] and W == 1:
         single = HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta)
         single.step_many(dt, 2); single.sync()

@@ -145,9 +145,6 @@ class _ThreadComm:
             def all_to_all_counts(self, send_counts):
                 return np.array([c[rank] for c in self._swap(np.array(send_counts))], dtype=np.int64)
 
-            def all_gather_counts(self, mine):
-                return np.array(self._swap(int(mine)), dtype=np.int64)
-
             def all_to_all_rows(self, recv, send, recv_counts, send_counts):
                 import torch
                 got = self._swap((send, np.array(send_counts)))
@@ -211,17 +208,17 @@ def test_owner_mode_three_ranks_agree_with_single_handle(gpu):
     for r in range(world):
         err = np.abs(out[r][0] - ref_p).max() / scale
         verr = np.abs(out[r][1] - ref_v).max() / np.abs(ref_v).max()
-        print(f"rank {r}: owns {engines[r].sim.n} bodies, received tree rows {engines[r].let_counts.tolist()} "
+        print(f"rank {r}: owns {engines[r].sim.n} bodies, received tree rows per source {engines[r].let_counts.tolist()} "
               f"(single-GPU tree {own_nodes}), sent {engines[r].wire_bytes} B, migrated {engines[r].migrated}; "
               f"pos err {err:.2e} vel err {verr:.2e}")
         assert err <= 1e-6 and verr <= 1e-4
         assert np.array_equal(out[r][0], out[0][0])  # every rank gathered the same state
     counts = [e.sim.n for e in engines]
     assert sum(counts) == n and max(counts) <= 1.1 * n / world + 64  # re-balanced by the sampled splitters
-    # a rank ships (at most) its tree; at 20 k bodies per rank nearly all of it is "near" for the neighbours -
-    # the pruning pays at bench sizes (scripts/gpu_exchange_probe.py: 3-12 % of the tree at 1 M per rank)
+    # a rank receives pruned trees; at 20 k bodies per rank much of a neighbour's tree is still "near" - the
+    # pruning pays at bench sizes (scripts/gpu_let_probe.py)
     for e in engines:
-        assert 0 < e.let_counts[(e.rank + 1) % world] <= 1.6 * max(counts)
+        assert e.let_counts[e.rank] == 0 and 0 < e.let_counts[(e.rank + 1) % world] <= 1.6 * max(counts)
     # an owner handle refuses the single-GPU entry points
     with pytest.raises(RuntimeError, match="owner mode"):
         engines[0].sim.step(dt)

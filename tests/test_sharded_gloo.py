@@ -91,8 +91,8 @@ class OracleLetEngine:
         self.send_rows = torch.zeros((self.cap, 8), dtype=f64)
         self.recv_rows = torch.zeros((self.cap, 8), dtype=f64)
         self.bbox, self.boxes = torch.zeros(6, dtype=f64), torch.zeros(world * 6, dtype=f64)
-        self.let_mine = torch.zeros((self.cap, 4), dtype=f64)
-        self.let_all = torch.zeros((self.cap * world, 4), dtype=f64)
+        self.let_send = torch.zeros((self.cap * world, 4), dtype=f64)
+        self.let_recv = torch.zeros((self.cap * world, 4), dtype=f64)
         self.wire_bytes, self.migrated, self.let_counts = 0, 0, np.zeros(world, dtype=np.int64)
 
     def wait(self):
@@ -134,9 +134,15 @@ class OracleLetEngine:
         self.bbox.copy_(torch.from_numpy(np.concatenate([lo, hi])))
 
     def op_export_let(self):
+        # the same (unpruned) tree for every other rank, packed one destination after the other
         n = len(self.pos)
-        self.let_mine[:n] = torch.from_numpy(np.concatenate([self.pos, self.mass[:, None]], axis=1))
-        return n
+        rows = torch.from_numpy(np.concatenate([self.pos, self.mass[:, None]], axis=1))
+        counts, off = np.zeros(self.world, dtype=np.int64), 0
+        for j in range(self.world):
+            if j != self.rank:
+                self.let_send[off:off + n] = rows
+                counts[j], off = n, off + n
+        return counts
 
     def _tree_forces(self, src_pos, src_mass, bounds, shift_ids):
         R = self.R
@@ -152,11 +158,12 @@ class OracleLetEngine:
     def op_step(self, counts, dt):
         b = float(self.maxabs[0]) * 1.1 + 10.0
         acc = self._tree_forces(self.pos, self.mass, b, False)
-        rows = self.let_all.numpy()
+        rows, off = self.let_recv.numpy(), 0
         for j in range(self.world):
             if j == self.rank or counts[j] == 0:
                 continue
-            r = rows[j * self.cap: j * self.cap + int(counts[j])]
+            r = rows[off: off + int(counts[j])]
+            off += int(counts[j])
             acc += self._tree_forces(np.ascontiguousarray(r[:, 0:3]), np.ascontiguousarray(r[:, 3]), b, True)
         self.vel = (self.vel + acc * dt) * self.damping
         self.pos = self.pos + self.vel * dt
@@ -190,7 +197,7 @@ def _let_worker(rank, world, port, steps, outdir):
 
 def test_owner_mode_two_rank_gloo_matches_oracle(tmp_path, oracle):
     """LetBarnesHut over gloo, world 2: all-reduce MAX, all-gather of key samples, all-to-all of counts and of
-    the migrating rows (variable splits), all-gather of boxes / tree sizes / trees, on-demand state gather.
+    the migrating rows (variable splits), all-gather of boxes, all-to-all of tree sizes and trees, state gather.
     Two partial trees instead of one whole tree near the rank boundary: positions agree with the plain
     single-process oracle loop to 1e-6 of the largest coordinate, not bit for bit."""
     steps = 4
