@@ -432,23 +432,23 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(MomentSrc src, const int3
                                                        Moment *__restrict__ S, int32_t *__restrict__ Pex) {
     __shared__ ScanVal lds[kBlock / 64];
     __shared__ ScanVal excl[kBlock];
-    // blocked layout: each thread owns kScanItems consecutive elements.  The items are loaded twice (thread
-    // sum, then the running prefix) instead of being kept: 8 x 17 registers would leave two waves per SIMD.
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    ScanVal sum = sv_zero();
-#pragma unroll 2
-    for (int k = 0; k < kScanItems; k++) sum = sv_add(sum, sv_load(src, cnt, base + k, n));
-    ScanVal total;
-    const ScanVal inc = block_inclusive_scan(sum, lds, total);
-    ScanVal run = sv_add(tile_off[blockIdx.x], block_exclusive_from_inclusive(inc, excl));
-#pragma unroll 2
+    // The tile is swept in kScanItems rounds of kBlock consecutive elements: loads and the 68-byte stores are
+    // coalesced (a thread that owned 8 consecutive elements wrote at a 544-byte stride: 548 us at 10 M bodies).
+    // One block scan per round instead of one per tile - arithmetic is the cheap part here.
+    ScanVal carry = tile_off[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+#pragma unroll 1
     for (int k = 0; k < kScanItems; k++) {
-        const int64_t i = base + k;
+        const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+        const ScanVal v = sv_load(src, cnt, i, n);
+        ScanVal total;
+        const ScanVal inc = block_inclusive_scan(v, lds, total);
+        const ScanVal run = sv_add(carry, block_exclusive_from_inclusive(inc, excl));
         if (i <= n) {  // entry n receives the grand totals
             S[i] = Moment{run.m.h, run.m.l, run.x.h, run.x.l, run.y.h, run.y.l, run.z.h, run.z.l};
             Pex[i] = run.c;
         }
-        run = sv_add(run, sv_load(src, cnt, i, n));
+        carry = sv_add(carry, total);
     }
 }
 
@@ -1786,7 +1786,7 @@ struct nbmi_sim {
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
-    int sort_bits = 40;  // upper-word bits the radix sort looks at (NBMI_SORT_BITS); widened when long runs show up
+    int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
@@ -1865,6 +1865,15 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     // radix sort on the top sort_bits bits of the upper word, then the tie-fix completes the 126-bit order
+    if (s->sort_bits == 0) {
+        // enough levels that cells of that level hold about one body on average, plus three: 3 (log8 n + 3) bits,
+        // rounded up to whole 8-bit digit passes (1 M bodies: 32 bits = 4 passes; 10 M: 40 = 5)
+        int levels = 3;
+        for (int64_t c = 1; c < n; c *= 8) levels++;
+        int bits = ((3 * levels + 7) / 8) * 8;
+        if (bits < 16) bits = 16;
+        s->sort_bits = bits < 63 ? bits : 63;
+    }
     const int shift = 63 - s->sort_bits;
     NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
                                             (size_t)n, shift, 63, st));
