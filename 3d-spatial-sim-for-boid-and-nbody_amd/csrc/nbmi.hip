@@ -1866,9 +1866,10 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     // radix sort on the top sort_bits bits of the upper word, then the tie-fix completes the 126-bit order
     if (s->sort_bits == 0) {
-        // enough levels that cells of that level hold about one body on average, plus three: 3 (log8 n + 3) bits,
-        // rounded up to whole 8-bit digit passes (1 M bodies: 32 bits = 4 passes; 10 M: 40 = 5)
-        int levels = 3;
+        // enough levels that cells of that level hold about one body on average, plus four: 3 (log8 n + 4) bits,
+        // rounded up to whole 8-bit digit passes (1 M and 10 M bodies: 40 bits = 5 passes; measured at 1 M: with
+        // 32 bits the tie-fix's runs in the galaxy core cost more (sort phase 0.25 ms) than the pass saved (0.15))
+        int levels = 4;
         for (int64_t c = 1; c < n; c *= 8) levels++;
         int bits = ((3 * levels + 7) / 8) * 8;
         if (bits < 16) bits = 16;
