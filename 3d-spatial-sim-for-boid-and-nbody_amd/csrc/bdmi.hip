@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bdmi.h"
@@ -189,6 +190,14 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
     const int64_t r = logical_block(blockIdx.x, gridDim.x, xcd_contiguous) * kBlock + threadIdx.x;
     if (r >= n) return;
     const double4 pi4 = b.p[r], vi4 = b.v[r], ci4 = b.c[r];
+    if (kPhysics && b.id[r] < 0) {
+        // a ghost (slab mode: a neighbour slab's boid inside the halo): visible to the others, owned elsewhere
+        a.px[r] = pi4.x; a.py[r] = pi4.y; a.pz[r] = pi4.z;
+        a.vx[r] = vi4.x; a.vy[r] = vi4.y; a.vz[r] = vi4.z;
+        a.cr[r] = ci4.x; a.cg[r] = ci4.y; a.cb[r] = ci4.z;
+        a.id[r] = b.id[r];
+        return;
+    }
     const double pix = pi4.x, piy = pi4.y, piz = pi4.z;
     const double vix = vi4.x, viy = vi4.y, viz = vi4.z;
     const double cir = ci4.x, cig = ci4.y, cib = ci4.z;
@@ -325,6 +334,81 @@ __global__ __launch_bounds__(kBlock) void k_cells_out(Boids a, int64_t n, GridP 
     out[a.id[r]] = cx + cy * g.dim + cz * g.dim * g.dim;
 }
 
+// ---- slab mode (multi-GPU): selections of rows by a predicate, in row order ------------------------------
+// what = 0: owned rows (id >= 0); 1: owned rows in the LEFT halo zone (x < x_lo + cell); 2: RIGHT (x >= x_hi - cell)
+struct SlabSel {
+    const double *px;
+    const int32_t *id;
+    int what;
+    double lo_edge, hi_edge;
+    __device__ bool operator()(int64_t r) const {
+        if (id[r] < 0) return false;
+        if (what == 0) return true;
+        return what == 1 ? px[r] < lo_edge : px[r] >= hi_edge;
+    }
+};
+__global__ __launch_bounds__(kBlock) void k_sel_count(SlabSel sel, int64_t n, uint32_t *__restrict__ tile_cnt) {
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * vis::kItems;
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < vis::kItems; k++) c += (base + k < n && sel(base + k)) ? 1u : 0u;
+    unsigned total;
+    (void)vis::block_exclusive_scan(c, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+}
+// selected rows -> packed rows {p, v, c, id} of 10 doubles (dst_rows) or -> the SoA arrays `dst` (compaction)
+__global__ __launch_bounds__(kBlock) void k_sel_emit(SlabSel sel, Boids src, int64_t n, const uint32_t *__restrict__ tile_cnt,
+                                                     Boids dst, double *__restrict__ dst_rows) {
+    const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * vis::kItems;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < vis::kItems; k++) m |= ((base + k < n && sel(base + k)) ? 1u : 0u) << k;
+    unsigned total;
+    int64_t slot = (int64_t)tile_cnt[blockIdx.x] + vis::block_exclusive_scan(__popc(m), &total);
+#pragma unroll
+    for (int k = 0; k < vis::kItems; k++) {
+        if (!((m >> k) & 1u)) continue;
+        const int64_t r = base + k;
+        if (dst_rows) {
+            double *o = dst_rows + 10 * slot;
+            o[0] = src.px[r]; o[1] = src.py[r]; o[2] = src.pz[r];
+            o[3] = src.vx[r]; o[4] = src.vy[r]; o[5] = src.vz[r];
+            o[6] = src.cr[r]; o[7] = src.cg[r]; o[8] = src.cb[r];
+            o[9] = (double)src.id[r];
+        } else {
+            dst.px[slot] = src.px[r]; dst.py[slot] = src.py[r]; dst.pz[slot] = src.pz[r];
+            dst.vx[slot] = src.vx[r]; dst.vy[slot] = src.vy[r]; dst.vz[slot] = src.vz[r];
+            dst.cr[slot] = src.cr[r]; dst.cg[slot] = src.cg[r]; dst.cb[slot] = src.cb[r];
+            dst.id[slot] = src.id[r];
+        }
+        slot++;
+    }
+}
+// owned rows that have left the slab stay for this step as ghosts (their new owner got a copy)
+__global__ __launch_bounds__(kBlock) void k_slab_demote(Boids a, int64_t n, double x_lo, double x_hi) {
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= n) return;
+    const double x = a.px[r];
+    if (a.id[r] >= 0 && !(x >= x_lo && x < x_hi)) a.id[r] = -1 - a.id[r];
+}
+// received rows: inside the slab -> owned, else a ghost
+__global__ __launch_bounds__(kBlock) void k_slab_append(Boids a, int64_t at, const double *__restrict__ rows, int64_t count,
+                                                        double x_lo, double x_hi) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const double *o = rows + 10 * k;
+    const int64_t r = at + k;
+    a.px[r] = o[0]; a.py[r] = o[1]; a.pz[r] = o[2];
+    a.vx[r] = o[3]; a.vy[r] = o[4]; a.vz[r] = o[5];
+    a.cr[r] = o[6]; a.cg[r] = o[7]; a.cb[r] = o[8];
+    const int32_t gid = (int32_t)o[9];
+    a.id[r] = (o[0] >= x_lo && o[0] < x_hi) ? gid : -1 - gid;
+}
+__global__ __launch_bounds__(kBlock) void k_set_ids(const int32_t *__restrict__ ids, int32_t *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = ids[i];
+}
+
 inline int nblocks(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
 
 }  // namespace
@@ -339,6 +423,12 @@ struct bdmi_flock {
     hipStream_t stream = nullptr;
     Boids A = {};
     BoidsAoS B = {};
+    // slab mode (multi-GPU): rows [0, n) = owned boids and this step's ghosts; T = scratch for compactions
+    bool slab = false;
+    int64_t cap = 0;
+    double x_lo = 0, x_hi = 0;
+    int has_left = 0, has_right = 0;
+    Boids T = {};
     uint32_t *keys = nullptr, *keys_s = nullptr, *idx = nullptr, *perm = nullptr;
     uint2 *occ = nullptr;          // per 32 cells: {occupancy bits, rank of the first non-empty cell}
     int32_t *cell_start = nullptr;    // first sorted boid of the k-th non-empty cell; [count] = n
@@ -441,20 +531,22 @@ void bdmi_destroy(bdmi_flock *f) {
 
 static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, const double *col) {
     const int64_t n = f->n;
+    const int64_t c = f->cap > n ? f->cap : n;  // rows allocated (slab mode keeps head room for ghosts / immigrants)
     NBMI_HIP_CHECK(hipSetDevice(f->device));
     NBMI_HIP_CHECK(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking));
     for (auto &e : f->ev) NBMI_HIP_CHECK(hipEventCreate(&e));
     f->occ_words = (f->num_cells + 31) / 32;
-    if (alloc_boids(f, &f->A, n)) return -2;
-    if (dev_alloc(f, &f->B.p, n) || dev_alloc(f, &f->B.v, n) || dev_alloc(f, &f->B.c, n) || dev_alloc(f, &f->B.id, n))
+    if (alloc_boids(f, &f->A, c)) return -2;
+    if (f->slab && alloc_boids(f, &f->T, c)) return -2;
+    if (dev_alloc(f, &f->B.p, c) || dev_alloc(f, &f->B.v, c) || dev_alloc(f, &f->B.c, c) || dev_alloc(f, &f->B.id, c))
         return -2;
-    if (dev_alloc(f, &f->keys, n) || dev_alloc(f, &f->keys_s, n) || dev_alloc(f, &f->idx, n) ||
-        dev_alloc(f, &f->perm, n) || dev_alloc(f, &f->occ, (size_t)f->occ_words) ||
-        dev_alloc(f, &f->cell_start, (size_t)n + 2) ||
-        dev_alloc(f, &f->tile_cnt, (size_t)vis::tiles_for(n) + 2) || dev_alloc(f, &f->occupied, 1) ||
-        dev_alloc(f, &f->stage, (size_t)12 * (n ? n : 1)))
+    if (dev_alloc(f, &f->keys, c) || dev_alloc(f, &f->keys_s, c) || dev_alloc(f, &f->idx, c) ||
+        dev_alloc(f, &f->perm, c) || dev_alloc(f, &f->occ, (size_t)f->occ_words) ||
+        dev_alloc(f, &f->cell_start, (size_t)c + 2) ||
+        dev_alloc(f, &f->tile_cnt, (size_t)vis::tiles_for(c) + 2) || dev_alloc(f, &f->occupied, 1) ||
+        dev_alloc(f, &f->stage, (size_t)12 * (c ? c : 1)))
         return -2;
-    f->tmp_sort_bytes = nbmi::sort_pairs32_temp_bytes((size_t)n, 0, f->key_bits);
+    f->tmp_sort_bytes = nbmi::sort_pairs32_temp_bytes((size_t)c, 0, f->key_bits);
     char *t = nullptr;
     if (dev_alloc(f, &t, f->tmp_sort_bytes + 256)) return -2;
     f->tmp_sort = t;
@@ -470,8 +562,9 @@ static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, c
     return 0;
 }
 
-bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const double *col, const double *params,
-                        int device) {
+static bdmi_flock *bd_create(int64_t n, const double *pos, const double *vel, const double *col, const double *params,
+                             int device, bool slab, int64_t capacity, const int32_t *ids, double x_lo, double x_hi,
+                             int has_left, int has_right) {
     nbmi::clear_error();
     if (n < 0 || n > 1000000000 || !params || (n > 0 && (!pos || !vel || !col))) {
         nbmi::set_error("bdmi_create: bad arguments (n=%lld)", (long long)n);
@@ -480,6 +573,10 @@ bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const d
     const double bounds = params[0], perception = params[5], margin = params[1];
     if (!(bounds > 0) || !(perception > 0) || !(margin > 0)) {
         nbmi::set_error("bdmi_create: bounds, perception_radius and wall_margin must be > 0");
+        return nullptr;
+    }
+    if (slab && (capacity < n || capacity < 1 || (n > 0 && !ids) || !(x_hi - x_lo >= 2 * perception))) {
+        nbmi::set_error("bdmi_create_slab: capacity < n, missing ids, or a slab narrower than two cells");
         return nullptr;
     }
     int count = 0;
@@ -495,6 +592,8 @@ bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const d
     if (const char *e = getenv("BDMI_XCD")) f->xcd_contiguous = atoi(e) != 0;  // measurement knob
     f->n = n;
     f->device = device;
+    f->slab = slab; f->cap = slab ? capacity : 0;
+    f->x_lo = x_lo; f->x_hi = x_hi; f->has_left = has_left; f->has_right = has_right;
     memcpy(f->params, params, sizeof(f->params));
     // Flock.__init__ grid (flock.py:478-481)
     f->grid.cell_size = perception;
@@ -510,13 +609,144 @@ bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const d
     f->num_cells = (int64_t)f->grid.dim * f->grid.dim * f->grid.dim;
     f->key_bits = 1;
     while (((int64_t)1 << f->key_bits) < f->num_cells) f->key_bits++;
-    if (bd_create_impl(f, pos, vel, col) != 0) {
+    int rc = bd_create_impl(f, pos, vel, col);
+    if (rc == 0 && slab && n > 0) {  // global ids instead of row numbers
+        hipError_t e = hipMemcpyAsync(f->stage, ids, (size_t)n * 4, hipMemcpyHostToDevice, f->stream);
+        if (e == hipSuccess) {
+            k_set_ids<<<nblocks(n), kBlock, 0, f->stream>>>((const int32_t *)f->stage, f->A.id, n);
+            e = hipStreamSynchronize(f->stream);
+        }
+        if (e != hipSuccess) { nbmi::set_error("bdmi_create_slab: id upload failed: %s", hipGetErrorString(e)); rc = -2; }
+    }
+    if (rc != 0) {
         std::string keep = nbmi::get_error();
         bdmi_destroy(f);
         nbmi::set_error("%s", keep.c_str());
         return nullptr;
     }
     return f;
+}
+
+bdmi_flock *bdmi_create(int64_t n, const double *pos, const double *vel, const double *col, const double *params,
+                        int device) {
+    return bd_create(n, pos, vel, col, params, device, false, 0, nullptr, 0.0, 0.0, 0, 0);
+}
+
+// ---- slab mode --------------------------------------------------------------------------
+bdmi_flock *bdmi_create_slab(int64_t n, const double *pos, const double *vel, const double *col, const int32_t *ids,
+                             int64_t capacity, const double *params, double x_lo, double x_hi, int has_left, int has_right,
+                             int device) {
+    return bd_create(n, pos, vel, col, params, device, true, capacity, ids, x_lo, x_hi, has_left, has_right);
+}
+
+namespace {
+// rows selected by `sel`, in row order, to packed rows or to the SoA arrays `dst`; the count stays on the device
+int enqueue_select(bdmi_flock *f, const SlabSel &sel, int64_t n, Boids dst, double *dst_rows) {
+    const int64_t ntiles = vis::tiles_for(n);
+    k_sel_count<<<(int)ntiles, kBlock, 0, f->stream>>>(sel, n, f->tile_cnt);
+    vis::k_scan_tiles<<<1, vis::kBlock, 0, f->stream>>>(f->tile_cnt, ntiles);
+    k_sel_emit<<<(int)ntiles, kBlock, 0, f->stream>>>(sel, f->A, n, f->tile_cnt, dst, dst_rows);
+    NBMI_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int slab_check(bdmi_flock *f, const char *what) {
+    if (int rc = check(f)) return rc;
+    if (!f->slab) { nbmi::set_error("%s: not a slab-mode handle (bdmi_create_slab)", what); return -1; }
+    return 0;
+}
+// drop the ghosts: owned rows to the front, in row order
+int slab_compact_owned(bdmi_flock *f, int64_t *n_owned) {
+    uint32_t total = 0;
+    if (f->n > 0) {
+        const SlabSel own{f->A.px, f->A.id, 0, 0.0, 0.0};
+        if (int rc = enqueue_select(f, own, f->n, f->T, nullptr)) return rc;
+        NBMI_HIP_CHECK(hipMemcpyAsync(&total, f->tile_cnt + vis::tiles_for(f->n), 4, hipMemcpyDeviceToHost, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+        std::swap(f->A, f->T);
+    }
+    f->n = total;
+    *n_owned = total;
+    return 0;
+}
+}  // namespace
+
+int64_t bdmi_slab_count(bdmi_flock *f) {
+    if (!f || !f->slab) return -1;
+    int64_t n = 0;
+    if (slab_compact_owned(f, &n)) return -1;
+    return n;
+}
+
+int bdmi_slab_export(bdmi_flock *f, void *dev_left, int64_t *n_left, void *dev_right, int64_t *n_right) {
+    if (int rc = slab_check(f, "bdmi_slab_export")) return rc;
+    if (!n_left || !n_right || (f->has_left && !dev_left) || (f->has_right && !dev_right)) {
+        nbmi::set_error("bdmi_slab_export: null buffer");
+        return -1;
+    }
+    *n_left = *n_right = 0;
+    int64_t owned = 0;
+    if (int rc = slab_compact_owned(f, &owned)) return rc;  // last step's ghosts are gone
+    if (owned == 0) return 0;
+    const double cell = f->grid.cell_size;
+    uint32_t cl = 0, cr = 0;
+    const int64_t ntiles = vis::tiles_for(owned);
+    if (f->has_left) {
+        const SlabSel sel{f->A.px, f->A.id, 1, f->x_lo + cell, 0.0};
+        if (int rc = enqueue_select(f, sel, owned, Boids{}, (double *)dev_left)) return rc;
+        NBMI_HIP_CHECK(hipMemcpyAsync(&cl, f->tile_cnt + ntiles, 4, hipMemcpyDeviceToHost, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    }
+    if (f->has_right) {
+        const SlabSel sel{f->A.px, f->A.id, 2, 0.0, f->x_hi - cell};
+        if (int rc = enqueue_select(f, sel, owned, Boids{}, (double *)dev_right)) return rc;
+        NBMI_HIP_CHECK(hipMemcpyAsync(&cr, f->tile_cnt + ntiles, 4, hipMemcpyDeviceToHost, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    }
+    // boids that have left the slab were just handed over: here they are ghosts for this step.  (Slabs at the
+    // two ends of the domain keep their outer side: the walls turn those boids back.)
+    k_slab_demote<<<nblocks(owned), kBlock, 0, f->stream>>>(f->A, owned, f->has_left ? f->x_lo : -INFINITY,
+                                                           f->has_right ? f->x_hi : INFINITY);
+    NBMI_HIP_CHECK(hipGetLastError());
+    *n_left = cl;
+    *n_right = cr;
+    return 0;
+}
+
+int bdmi_slab_import(bdmi_flock *f, const void *dev_rows, int64_t count) {
+    if (int rc = slab_check(f, "bdmi_slab_import")) return rc;
+    if (count < 0 || (count > 0 && !dev_rows)) { nbmi::set_error("bdmi_slab_import: bad arguments"); return -1; }
+    if (f->n + count > f->cap) {
+        nbmi::set_error("bdmi_slab_import: %lld + %lld boids exceed the capacity %lld", (long long)f->n, (long long)count,
+                        (long long)f->cap);
+        return -4;
+    }
+    if (count == 0) return 0;
+    k_slab_append<<<nblocks(count), kBlock, 0, f->stream>>>(f->A, f->n, (const double *)dev_rows, count,
+                                                           f->has_left ? f->x_lo : -INFINITY, f->has_right ? f->x_hi : INFINITY);
+    NBMI_HIP_CHECK(hipGetLastError());
+    f->n += count;
+    return 0;
+}
+
+int bdmi_slab_get(bdmi_flock *f, double *rows10, int64_t capacity, int64_t *count) {
+    if (int rc = slab_check(f, "bdmi_slab_get")) return rc;
+    if (!count) { nbmi::set_error("bdmi_slab_get: null count"); return -1; }
+    *count = 0;
+    if (f->n == 0) return 0;
+    // owned rows {p, v, c, id}, packed, through the staging buffer (12 doubles per row are reserved)
+    const SlabSel own{f->A.px, f->A.id, 0, 0.0, 0.0};
+    if (int rc = enqueue_select(f, own, f->n, Boids{}, f->stage)) return rc;
+    uint32_t total = 0;
+    NBMI_HIP_CHECK(hipMemcpyAsync(&total, f->tile_cnt + vis::tiles_for(f->n), 4, hipMemcpyDeviceToHost, f->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    *count = total;
+    const int64_t rows = (int64_t)total < capacity ? (int64_t)total : capacity;
+    if (rows > 0) {
+        if (!rows10) { nbmi::set_error("bdmi_slab_get: null output"); return -1; }
+        NBMI_HIP_CHECK(hipMemcpyAsync(rows10, f->stage, (size_t)rows * 80, hipMemcpyDeviceToHost, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    }
+    return 0;
 }
 
 int bdmi_step(bdmi_flock *f, double dt, int substeps) {

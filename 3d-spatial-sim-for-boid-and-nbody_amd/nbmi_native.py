@@ -63,6 +63,11 @@ PROTOTYPES = {
     "nbmi_frame_set_previous": (C.c_int, [_vp, _vp, _vp]),
     "nbmi_debug_sort_pairs": (C.c_int, [C.c_int, _i64, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "bdmi_create": (_vp, [_i64, _vp, _vp, _vp, _vp, C.c_int]),
+    "bdmi_create_slab": (_vp, [_i64, _vp, _vp, _vp, _vp, _i64, _vp, _dbl, _dbl, C.c_int, C.c_int, C.c_int]),
+    "bdmi_slab_count": (_i64, [_vp]),
+    "bdmi_slab_export": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "bdmi_slab_import": (C.c_int, [_vp, _vp, _i64]),
+    "bdmi_slab_get": (C.c_int, [_vp, _vp, _i64, _vp]),
     "bdmi_destroy": (None, [_vp]),
     "bdmi_last_error": (C.c_char_p, []),
     "bdmi_step": (C.c_int, [_vp, _dbl, C.c_int]),

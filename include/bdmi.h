@@ -56,6 +56,32 @@ int bdmi_enable_timers(bdmi_flock *f, int enable);
 int bdmi_get_timers(bdmi_flock *f, double *ms3, int64_t *count, int reset);
 
 
+/* ---- multi-GPU: x-slabs with a one-cell halo -----------------------------------------
+ * A rank owns the boids with x_lo <= x < x_hi (a whole number of cell planes, at least two cells wide); the
+ * neighbour sweep needs the boids within one cell (= the perception radius, flock.py:479) on the other side
+ * of each face.  The handle holds the owned boids plus this step's ghosts (read-only copies of the
+ * neighbours' boundary boids).  A boid moves at most max_speed * dt << one cell per step, so it can only
+ * ever change to an adjacent slab, and ONE exchange per step carries migrants and halo alike:
+ *
+ *   bdmi_slab_export(h, left, &nl, right, &nr)   drop last step's ghosts; rows {p, v, c, global id} (10 doubles)
+ *                                                of the owned boids with x < x_lo + cell -> `left`, with
+ *                                                x >= x_hi - cell -> `right` (device buffers, counts on the
+ *                                                host); owned boids now outside the slab stay as ghosts
+ *        exchange with the two neighbours        (send/recv or all-to-all-v on the host framework)
+ *   bdmi_slab_import(h, rows, count)             received rows: inside the slab -> owned, else ghosts
+ *   bdmi_step(h, dt, 1)                          Flock.update for the owned boids; ghosts only take part as
+ *                                                neighbours
+ *
+ * The candidate set of every owned boid equals the single-GPU one, so forces agree to float64 summation
+ * order.  bdmi_slab_get returns the owned rows (10 doubles each, any order). */
+bdmi_flock *bdmi_create_slab(int64_t n, const double *positions_xyz, const double *velocities_xyz, const double *colors_rgb,
+                             const int32_t *global_ids, int64_t capacity, const double *params11, double x_lo, double x_hi,
+                             int has_left_neighbour, int has_right_neighbour, int device);
+int64_t bdmi_slab_count(bdmi_flock *f);
+int bdmi_slab_export(bdmi_flock *f, void *dev_left_rows, int64_t *n_left, void *dev_right_rows, int64_t *n_right);
+int bdmi_slab_import(bdmi_flock *f, const void *dev_rows, int64_t count);
+int bdmi_slab_get(bdmi_flock *f, double *rows10, int64_t capacity, int64_t *count);
+
 /* ---- render-side reduction ------------------------------------------ */
 /* Flock._compute_visibility + _build_vertices on the device (flock.py:680-728): frustum test of
  * compute_visibility_numba (:311-348; z < 0.5 or z > fog_end hidden), np.where order (ascending

@@ -144,3 +144,57 @@ def test_config5_two_million_boids_properties(gpu, oracle):
     assert np.isfinite(fl.positions).all() and sp.max() <= 25.0 * (1 + 1e-12)
     assert fl.colors.min() >= 0.0 and fl.colors.max() <= 1.0
     fl.close()
+
+
+def test_slab_sharded_flock_equals_single_handle(gpu):
+    """boids in x-slabs with a one-cell halo.  Three threads on one GPU play three ranks through
+    SlabFlock.step (neighbour exchange = all-to-all-v between threads); after 25 steps every boid has exactly one
+    owner, boids have migrated between slabs, and the state equals the single handle's to float64 summation
+    order (same candidate sets)."""
+    import threading
+    import nbmi_native as nat
+    from boids.flock import generate_initial_state
+    from boids.sharded import HipSlabEngine, SlabFlock
+    from test_gpu_sharded_record import _ThreadComm
+    np.random.seed(3)
+    n, bounds = 30_000, 60.0
+    pos, vel, col = generate_initial_state(n, bounds, 25.0)
+    from oracle import pyref
+    params = pyref.boids_params(bounds=bounds)
+    dt, steps, world = 1.0 / 60.0, 25, 3
+    lib = nat.load()
+    h = lib.bdmi_create(n, nat.ptr(pos), nat.ptr(vel), nat.ptr(col), nat.ptr(params), 0)
+    nat.check(lib.bdmi_step(h, dt, steps), "bdmi_step")
+    ref = [np.empty((n, 3)) for _ in range(3)]
+    nat.check(lib.bdmi_get_state(h, nat.ptr(ref[0]), nat.ptr(ref[1]), nat.ptr(ref[2])), "bdmi_get_state")
+    lib.bdmi_destroy(h)
+
+    comm = _ThreadComm(world)
+    engines = [HipSlabEngine(pos, vel, col, params, r, world) for r in range(world)]
+    start_ids = [set(e.owned_rows()[:, 9].astype(int)) for e in engines]
+    flocks = [SlabFlock(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    out, errs = [None] * world, []
+
+    def rank_main(r):
+        try:
+            flocks[r].step(dt, steps)
+            out[r] = flocks[r].gather_state(n)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+            comm.bar.abort()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not errs, errs
+    end_ids = [set(e.owned_rows()[:, 9].astype(int)) for e in engines]
+    moved = sum(len(a - b) for a, b in zip(start_ids, end_ids))
+    print(f"slabs: owned {[len(s) for s in end_ids]}, boids that changed owner {moved}, halo rows sent by rank 1 last step "
+          f"{engines[1].sent_rows}")
+    assert moved > 0 and sum(len(s) for s in end_ids) == n
+    for r in range(world):
+        for got, want, what in zip(out[r], ref, ("positions", "velocities", "colors")):
+            err = np.abs(got - want).max()
+            assert err <= 1e-9, (r, what, err)
+    for e in engines:
+        e.close()
