@@ -131,7 +131,7 @@ class SlabFlock:
         if self.world == 1:
             full = rows
         else:
-            cap = self.engine.cap
+            cap = n_total  # the same on every rank (the engines' own capacities differ)
             mine = torch.full((cap, ROW), -1.0, dtype=torch.float64)
             mine[: len(rows)] = torch.from_numpy(rows)
             mine = mine.to(self.engine.send.device)
