@@ -281,6 +281,46 @@ def bench_boids(args, n, dt):
     print(json.dumps(out), flush=True)
 
 
+def bench_boids_slabs(args, n, dt, world, rank, dev):
+    """BASELINE config 5 over N GPUs (strong scaling: the same 2 M boids, x-slabs of cell planes with a one-cell
+    halo, one neighbour exchange per step; boids/sharded.py)."""
+    import torch
+    import torch.distributed as dist
+    from boids.flock import generate_initial_state
+    from boids.sharded import HipSlabEngine, SlabFlock
+    from nbody.sharded import DistComm
+    from oracle import pyref  # parameter table only
+    np.random.seed(42)
+    pos, vel, col = generate_initial_state(n, 500.0, 25.0)
+    with contextlib.redirect_stdout(sys.stderr):
+        eng = HipSlabEngine(pos, vel, col, pyref.boids_params(), rank, world, device=dev)
+    del pos, vel, col
+    fl = SlabFlock(eng, rank, world, DistComm(dist, eng.device) if world > 1 else None)
+
+    def fence():
+        eng.wait()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    fl.step(dt, args.warmup)
+    fence()
+    t0 = time.perf_counter()
+    fl.step(dt, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    return {"metric": "boid-steps/sec (boids sep/align/cohesion sweep)", "value": n * args.steps / elapsed,
+            "unit": "boid-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic (reference Flock ICs, seed 42)",
+            "config": {"workload": "boids_2m", "boids": n, "bounds": 500.0, "perception_radius": 5.0, "dt": dt,
+                       "parallelism": f"x{world}: x-slabs of cell planes, one-cell halo + migrants in one all-to-all-v per step"},
+            "exchange": {"rows_sent_last_step_rank0": int(eng.sent_rows), "row_bytes": 80}}
+
+
 def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu_budget_s=25.0):
     """One N-body workload: K timed steps (barrier + synchronize on both sides, max over ranks), then at
     N = 1 a second pass with per-phase HIP events, the counted walk, and the CPU port beside it."""
@@ -458,7 +498,13 @@ def main():
 
     method = WORKLOADS[args.workload][7]
     if method == "boids":
-        assert world == 1, "boids run as replicas only (DESIGN.md section 6)"
+        if world > 1 or use_dist:
+            out = bench_boids_slabs(args, WORKLOADS[args.workload][1], WORKLOADS[args.workload][6], world, rank, dev)
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         return bench_boids(args, WORKLOADS[args.workload][1], WORKLOADS[args.workload][6])
 
     out = measure_nbody(args, args.workload, world, rank, dev, use_dist, args.steps, args.warmup)
