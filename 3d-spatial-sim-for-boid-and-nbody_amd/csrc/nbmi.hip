@@ -176,13 +176,19 @@ __global__ __launch_bounds__(kBlock) void k_maxabs(const double *__restrict__ x,
 __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, const double *__restrict__ y,
                                                  const double *__restrict__ z, int64_t n, TreeInfo *info,
                                                  uint64_t *__restrict__ key_hi, uint64_t *__restrict__ key_lo,
-                                                 uint32_t *__restrict__ idx) {
+                                                 uint32_t *__restrict__ idx, const uint8_t *__restrict__ dead = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     // bounds = max_extent * 1.1 + 10.0 with two roundings (no FMA contraction)
     const double maxabs = __longlong_as_double((long long)info->maxabs_bits);
     const double bounds = __dadd_rn(__dmul_rn(maxabs, 1.1), 10.0);
     if (i == 0) info->bounds = bounds;
     if (i >= n) return;
+    if (dead && dead[i]) {  // owner mode: this row's body now lives on another rank; all ones sorts behind every key
+        key_hi[i] = ~0ull;
+        key_lo[i] = ~0ull;
+        idx[i] = (uint32_t)i;
+        return;
+    }
     const double px = x[i], py = y[i], pz = z[i];
     double cx = 0.0, cy = 0.0, cz = 0.0, hs = bounds;
     uint64_t k[2];
@@ -1400,28 +1406,27 @@ __global__ __launch_bounds__(kBlock) void k_dest(const uint64_t *__restrict__ ke
     idx[i] = (uint32_t)i;
 }
 
-// counts per destination from the destination-sorted array
-__global__ void k_dest_counts(const uint32_t *__restrict__ dest_s, int64_t n, int world, int64_t *__restrict__ counts) {
-    const int j = threadIdx.x;
-    if (j >= world) return;
-    auto lower = [&](uint32_t v) {
-        int64_t lo = 0, hi = n;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (dest_s[mid] < v) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    counts[j] = lower((uint32_t)j + 1u) - lower((uint32_t)j);
+// owner mode, migration: flag row j of destination d = 1 if body i goes to rank d (d != me); dead[i] = leaves
+__global__ __launch_bounds__(kBlock) void k_emigrant_flags(const uint32_t *__restrict__ dest, int64_t n, int world, int me,
+                                                           int64_t stride, int32_t *__restrict__ flag, uint8_t *__restrict__ dead) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)dest[i];
+    for (int j = 0; j < world; j++) flag[(int64_t)j * stride + i] = (j == d && j != me) ? 1 : 0;
+    dead[i] = d != me ? 1 : 0;
 }
-
-// rows {x,y,z,vx,vy,vz,m,id} in the order `order` (grouped by destination, input order inside a group)
-__global__ __launch_bounds__(kBlock) void k_pack_rows_perm(Bodies cur, const uint32_t *__restrict__ order, int64_t n,
-                                                           double *__restrict__ rows) {
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t r = order[k];
-    double *o = rows + 8 * k;
-    o[0] = cur.x[r]; o[1] = cur.y[r]; o[2] = cur.z[r];
-    o[3] = cur.vx[r]; o[4] = cur.vy[r]; o[5] = cur.vz[r];
-    o[6] = cur.m[r]; o[7] = (double)cur.id[r];
+// emigrants' rows, grouped by destination (segment offsets from k_let_counts), current order inside a group
+__global__ __launch_bounds__(kBlock) void k_pack_emigrants(Bodies cur, const uint32_t *__restrict__ dest, int64_t n, int me,
+                                                           int64_t stride, const int32_t *__restrict__ slot,
+                                                           const int64_t *__restrict__ seg_off, double *__restrict__ rows) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)dest[i];
+    if (d == me) return;
+    double *o = rows + 8 * (seg_off[d] + slot[(int64_t)d * stride + i]);
+    o[0] = cur.x[i]; o[1] = cur.y[i]; o[2] = cur.z[i];
+    o[3] = cur.vx[i]; o[4] = cur.vy[i]; o[5] = cur.vz[i];
+    o[6] = cur.m[i]; o[7] = (double)cur.id[i];
 }
 
 // Where a rank's bodies are, for the pruning of the trees the others send it: tight bounding boxes of the
@@ -1438,10 +1443,14 @@ constexpr int kBoxesPerRank = 2048, kSuper = 32, kSupersPerRank = kBoxesPerRank 
 // flag[i] = 1 if node i is one of the cells / leaves whose bodies get a box
 __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
                                                       const int32_t *__restrict__ node_ref, const uint64_t *__restrict__ hi_s,
-                                                      const uint64_t *__restrict__ lo_s, int64_t num_nodes, int64_t n,
-                                                      int32_t *__restrict__ flag) {
+                                                      const uint64_t *__restrict__ lo_s, const TreeInfo *__restrict__ info,
+                                                      int64_t n, int32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_nodes) return;
+    const int64_t num_nodes = info->error ? 0 : info->num_nodes;
+    if (i >= num_nodes) {
+        flag[i] = 0;  // launched for the row budget: rows behind the tree count nothing
+        return;
+    }
     const int l = node_level[i];
     int f = 0;
     if (l <= kBoxLevelMax) {
@@ -1467,14 +1476,16 @@ __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ n
 // body ranges of the flagged nodes, in key order
 __global__ __launch_bounds__(kBlock) void k_box_ranges(const Node *__restrict__ nodes, const int32_t *__restrict__ node_ref,
                                                        const int32_t *__restrict__ flag, const int32_t *__restrict__ slot,
-                                                       int64_t num_nodes, int64_t n, int32_t *__restrict__ ranges /* 2 x kBoxesPerRank */) {
+                                                       const TreeInfo *__restrict__ info, int64_t rows, int64_t n,
+                                                       int32_t *__restrict__ ranges /* 2 x kBoxesPerRank */) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t num_nodes = info->error ? 0 : info->num_nodes;
     if (i >= num_nodes || !flag[i]) return;
     const int k = slot[i];
     if (k >= kBoxesPerRank) return;  // more cells than boxes: the last box takes everything from its cell on
     const int64_t nx = nodes[i].next_off / kNodeBytes;
     ranges[2 * k] = node_ref[i];
-    ranges[2 * k + 1] = (k == kBoxesPerRank - 1 && slot[num_nodes] > kBoxesPerRank) ? (int32_t)n
+    ranges[2 * k + 1] = (k == kBoxesPerRank - 1 && slot[rows] > kBoxesPerRank) ? (int32_t)n
                                                                                     : (int32_t)(nx < num_nodes ? node_ref[nx] : n);
 }
 // one workgroup per box: tight bounding box of the bodies [a, b) (empty box: lo = +inf > hi = -inf)
@@ -1772,7 +1783,9 @@ struct nbmi_sim {
     int64_t let_capacity = 0;   // rows of one locally essential tree in the exchange buffers
     int64_t node_extra = 0;     // node rows reserved behind the own tree for received trees
     uint64_t *let_split = nullptr;
-    uint32_t *let_dest = nullptr, *let_dest_s = nullptr, *let_order = nullptr;
+    uint8_t *let_dead = nullptr;   // rows whose body has just been handed to another rank
+    int64_t n_leaving = 0;
+    uint32_t *let_dest = nullptr;
     int64_t *let_counts = nullptr;
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
     double *let_supers = nullptr, *let_rankbox = nullptr;
@@ -1858,11 +1871,14 @@ int enqueue_maxabs(nbmi_sim *s) {
     return 0;
 }
 
-int enqueue_local_sort(nbmi_sim *s, int ev_base) {
-    const int64_t n = s->n;
+// n_sort rows are keyed and sorted (owner mode: rows of emigrants are still in place, flagged dead, and sort to
+// the end); the first n_live of the order are gathered for the tree
+int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_live = -1, const uint8_t *dead = nullptr) {
+    const int64_t n = n_sort < 0 ? s->n : n_sort;
+    if (n_live < 0) n_live = n;
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf];
-    k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx);
+    k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx, dead);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     // radix sort on the top sort_bits bits of the upper word, then the tie-fix completes the 126-bit order
     if (s->sort_bits == 0) {
@@ -1885,7 +1901,7 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base) {
     std::swap(s->hi_s, s->key_hi);
     s->t_hi = s->hi_s;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
-    k_gather<<<nblocks(n), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n, s->G, s->posm_s, s->p64_s, s->lo_s);
+    k_gather<<<nblocks(n_live), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s);
     return 0;
 }
 
@@ -2592,8 +2608,8 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
         s->let_stride = s->own_node_rows + 8;
         s->let_tile_stride = s->let_stride / kScanTile + 4;
         const size_t all = (size_t)s->let_stride * world;
-        if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) || dev_alloc(s, &s->let_dest_s, c) ||
-            dev_alloc(s, &s->let_order, c) || dev_alloc(s, &s->let_counts, 2 * kMaxWorld) ||
+        if (dev_alloc(s, &s->let_split, kMaxWorld) || dev_alloc(s, &s->let_dest, c) ||
+            dev_alloc(s, &s->let_counts, 2 * kMaxWorld) || dev_alloc(s, &s->let_dead, c) ||
             dev_alloc(s, &s->let_diff, all) || dev_alloc(s, &s->let_scan, all) || dev_alloc(s, &s->let_keep, all) ||
             dev_alloc(s, &s->let_tiles, (size_t)s->let_tile_stride * world) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
             dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
@@ -2662,53 +2678,60 @@ int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_sam
         return NBMI_ERR_ARG;
     }
     hipStream_t st = s->stream;
-    const int64_t n = s->n;
-    k_splitters<<<1, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, s->world, s->let_split);
+    const int64_t n = s->n, stride = s->let_stride;
+    const int W = s->world;
+    for (int j = 0; j < W; j++) counts[j] = 0;
+    k_splitters<<<1, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, W, s->let_split);
     if (n > 0) {
-        k_dest<<<nblocks(n), kBlock, 0, st>>>(s->key_hi, n, s->let_split, s->world, s->let_dest, s->idx);
-        // stable sort by destination: rows of one destination leave in their current (key) order
-        NBMI_HIP_CHECK(nbmi::sort_pairs_u32_u32(s->tmp_sort, s->tmp_sort_bytes, s->let_dest, s->let_dest_s, s->idx, s->let_order,
-                                                (size_t)n, 0, 8, st));
-        k_pack_rows_perm<<<nblocks(n), kBlock, 0, st>>>(s->buf[s->curbuf], s->let_order, n, (double *)dev_send_rows);
+        // only the bodies whose key has left this rank's range travel; everybody else stays where it is
+        k_dest<<<nblocks(n), kBlock, 0, st>>>(s->key_hi, n, s->let_split, W, s->let_dest, s->idx);
+        k_emigrant_flags<<<nblocks(n), kBlock, 0, st>>>(s->let_dest, n, W, s->rank, stride, s->let_keep, s->let_dead);
+        if (int rc = enqueue_iscan(s, s->let_keep, n, s->let_scan, W, stride)) return rc;
+        k_let_counts<<<1, 64, 0, st>>>(s->let_scan, n, stride, W, s->rank, s->let_counts);
+        k_pack_emigrants<<<nblocks(n), kBlock, 0, st>>>(s->buf[s->curbuf], s->let_dest, n, s->rank, stride, s->let_scan,
+                                                       s->let_counts + W, (double *)dev_send_rows);
+        NBMI_HIP_CHECK(hipGetLastError());
+        NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
     }
-    k_dest_counts<<<1, kMaxWorld, 0, st>>>(s->let_dest_s, n, s->world, s->let_counts);
-    NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)s->world * 8, hipMemcpyDeviceToHost, st));
     NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    int64_t left = 0;
+    for (int j = 0; j < W; j++) left += counts[j];
+    s->n_leaving = left;
     return 0;
 }
 
-int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_boxes) {
+int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes) {
     if (int rc = owner_check(s, "nbmi_owner_adopt")) return rc;
-    if (n_new < 0 || n_new > s->cap) {
-        nbmi::set_error("nbmi_owner_adopt: %lld bodies do not fit the capacity of %lld (raise the head room)", (long long)n_new,
-                        (long long)s->cap);
+    const int64_t n_old = s->n, n_work = n_old + n_recv, n_new = n_old - s->n_leaving + n_recv;
+    if (n_recv < 0 || n_work > s->cap) {
+        nbmi::set_error("nbmi_owner_adopt: %lld + %lld bodies do not fit the capacity of %lld (raise the head room)",
+                        (long long)n_old, (long long)n_recv, (long long)s->cap);
         return NBMI_ERR_CAPACITY;
     }
-    if ((n_new > 0 && !dev_recv_rows) || !dev_maxabs || !dev_boxes) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
+    if ((n_recv > 0 && !dev_recv_rows) || !dev_maxabs || !dev_boxes) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
     hipStream_t st = s->stream;
-    s->n = n_new; s->nt = n_new; s->shard_begin = 0; s->shard_end = n_new;
     Bodies cur = s->buf[s->curbuf];
-    if (n_new > 0) k_unpack_rows<<<nblocks(n_new), kBlock, 0, st>>>(cur, 0, n_new, (const double *)dev_recv_rows);
+    // immigrants go behind the rows already here; the emigrants' rows stay in place, flagged dead
+    if (n_recv > 0) {
+        k_unpack_rows<<<nblocks(n_recv), kBlock, 0, st>>>(cur, n_old, n_work, (const double *)dev_recv_rows);
+        NBMI_HIP_CHECK(hipMemsetAsync(s->let_dead + n_old, 0, (size_t)n_recv, st));
+    }
+    s->n = n_new; s->nt = n_new; s->shard_begin = 0; s->shard_end = n_new;
+    s->n_leaving = 0;
     // the tree header of this step: cleared, then the GLOBAL extent (every rank builds inside the same root cube)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
     if (n_new > 0) {
-        if (int rc = enqueue_local_sort(s, -1)) return rc;
+        if (int rc = enqueue_local_sort(s, -1, n_work, n_new, s->let_dead)) return rc;
         if (int rc = enqueue_global_tree(s)) return rc;
-        // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags)
-        const int64_t rows = s->own_node_rows;  // the node count lives on the device: launch for the row budget
-        (void)rows;
-        TreeInfo h;
-        NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
-        NBMI_HIP_CHECK(hipStreamSynchronize(st));
-        if (h.error) return check_device_error(s);
-        const int64_t nn = h.num_nodes;
-        k_box_flags<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, nn, n_new, s->let_keep);
-        if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan)) return rc;
+        // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags).  The node count lives on
+        // the device: launch for the row budget, the kernels stop at num_nodes themselves.
+        const int64_t rows = s->own_node_rows;
+        k_box_flags<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, s->info, n_new, s->let_keep);
+        if (int rc = enqueue_iscan(s, s->let_keep, rows, s->let_scan)) return rc;
         NBMI_HIP_CHECK(hipMemsetAsync(s->let_ranges, 0, sizeof(int32_t) * 2 * kBoxesPerRank, st));
-        k_box_ranges<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, nn, n_new, s->let_ranges);
-        k_range_boxes<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, s->let_ranges, s->let_scan + nn, (double *)dev_boxes);
+        k_box_ranges<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, s->info, rows, n_new, s->let_ranges);
+        k_range_boxes<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, s->let_ranges, s->let_scan + rows, (double *)dev_boxes);
     } else {
         std::vector<double> empty(6 * kBoxesPerRank);
         for (int k = 0; k < 6 * kBoxesPerRank; k++) empty[k] = (k % 6) < 3 ? INFINITY : -INFINITY;

@@ -224,8 +224,9 @@ class HipLetEngine:
     def op_partition(self, all_samples):
         return self.sim.owner_partition(all_samples.data_ptr(), all_samples.numel(), self.send_rows.data_ptr())
 
-    def op_adopt(self, rows, n_new):
-        self.sim.owner_adopt(rows.data_ptr(), n_new, self.maxabs.data_ptr(), self.bbox.data_ptr())
+    def op_adopt(self, rows, n_recv):
+        """`n_recv` immigrant rows join the bodies that stayed; keys, sort, octree, boxes."""
+        self.sim.owner_adopt(rows.data_ptr(), n_recv, self.maxabs.data_ptr(), self.bbox.data_ptr())
 
     def op_export_let(self):
         return self.sim.owner_export_let(self.boxes.data_ptr(), self.let_send.data_ptr())
@@ -272,18 +273,15 @@ class LetBarnesHut:
                 e.wait()
                 wire += 8 * e.SAMPLES
                 allsamp = e.all_samples
-            send_counts = e.op_partition(allsamp)
+            send_counts = e.op_partition(allsamp)  # rows of the bodies that leave, grouped by destination
+            n_recv = 0
             if W > 1:
                 recv_counts = self.comm.all_to_all_counts(send_counts)
-                n_new = int(recv_counts.sum())
-                if n_new > e.cap:
-                    raise RuntimeError(f"rank {self.rank}: {n_new} bodies after migration exceed the capacity {e.cap}")
+                n_recv = int(recv_counts.sum())
                 self.comm.all_to_all_rows(e.recv_rows, e.send_rows, recv_counts, send_counts)
                 e.wait()
-                wire += int(send_counts.sum() - send_counts[self.rank]) * ROW * 8
-                rows = e.recv_rows
-            else:
-                n_new, rows = int(send_counts[0]), e.send_rows
+                wire += int(send_counts.sum()) * ROW * 8
+            rows, n_new = e.recv_rows, n_recv
             e.op_adopt(rows, n_new)
             counts = np.zeros(W, dtype=np.int64)
             if W > 1:
@@ -300,7 +298,7 @@ class LetBarnesHut:
             e.op_step(counts, dt)
             e.let_counts = counts
             e.wire_bytes = wire
-            e.migrated = int(send_counts.sum() - send_counts[self.rank])
+            e.migrated = int(send_counts.sum())
 
     def gather_state(self):
         """Full (positions, velocities) float64 in the caller's original order, on every rank."""

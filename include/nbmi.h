@@ -152,10 +152,11 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *        all-reduce MAX of m
  *   nbmi_owner_sample(h, m, samples, S)             keys of the owned bodies in the global cube; S regular samples
  *        all-gather of the samples                  (world x S keys)
- *   nbmi_owner_partition(h, all, world*S, send, counts)   splitters at equal quantiles; rows {x,y,z,vx,vy,vz,m,id}
- *                                                   grouped by destination rank into `send`; counts[world] on the host
+ *   nbmi_owner_partition(h, all, world*S, send, counts)   splitters at equal quantiles; rows {x,y,z,vx,vy,vz,m,id} of
+ *                                                   the bodies that now belong to ANOTHER rank, grouped by destination
+ *                                                   in `send`; counts[world] on the host (counts[own rank] = 0)
  *        all-to-all of the counts, all-to-all-v of the rows  (only bodies that crossed a splitter travel)
- *   nbmi_owner_adopt(h, recv, n_new, m, box)        the received rows become the owned bodies: keys, sort, octree;
+ *   nbmi_owner_adopt(h, recv, n_recv, m, box)       the n_recv received rows join the bodies that stayed: keys, sort, octree;
  *                                                   box <- B = nbmi_owner_boxes_per_rank() bounding boxes (6 doubles
  *                                                   each: lo xyz, hi xyz), one per equal chunk of the key order
  *        all-gather of the boxes                    (world x B x 6 doubles)
@@ -179,7 +180,7 @@ int nbmi_owner_maxabs(nbmi_sim *sim, void *dev_maxabs);
 int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples);
 int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
                          int64_t *counts_host);
-int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_new, const void *dev_maxabs, void *dev_boxes);
+int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes);
 int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *counts_host);
 int nbmi_owner_step(nbmi_sim *sim, const void *dev_recv_let, const int64_t *recv_counts_host, double dt);
 

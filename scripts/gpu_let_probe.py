@@ -64,7 +64,7 @@ for W in Ws:
                 off += c
             _, t = timed(lambda: e.op_adopt(e.recv_rows, off))
             if rec and e.rank == 0: ph["adopt_sort_build"] += t
-            e.migrated = int(sc[e.rank].sum() - sc[e.rank][e.rank])
+            e.migrated = int(sc[e.rank].sum())
         boxes = torch.cat([e.bbox for e in E])
         lc = [np.zeros(W, dtype=np.int64) for _ in E]
         if W > 1:

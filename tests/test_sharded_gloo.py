@@ -120,15 +120,20 @@ class OracleLetEngine:
         split = np.array([valid[(j + 1) * len(valid) // W] for j in range(W - 1)], dtype=np.uint64)
         _, hi = self._keys()
         dest = np.searchsorted(split, hi, side="right")
-        order = np.argsort(dest, kind="stable")
-        rows = np.concatenate([self.pos, self.vel, self.mass[:, None], self.ids[:, None].astype(np.float64)], axis=1)[order]
-        self.send_rows[: len(rows)] = torch.from_numpy(rows)
-        return np.bincount(dest, minlength=W).astype(np.int64)
+        go = dest != self.rank
+        order = np.argsort(dest[go], kind="stable")
+        rows = np.concatenate([self.pos, self.vel, self.mass[:, None], self.ids[:, None].astype(np.float64)], axis=1)
+        out = rows[go][order]
+        self.send_rows[: len(out)] = torch.from_numpy(out)
+        counts = np.bincount(dest[go], minlength=W).astype(np.int64)
+        self._stay = rows[~go]
+        return counts
 
-    def op_adopt(self, rows, n_new):
-        r = rows[:n_new].numpy().copy()
+    def op_adopt(self, rows, n_recv):
+        r = np.concatenate([self._stay, rows[:n_recv].numpy().copy()])
         self.pos, self.vel = np.ascontiguousarray(r[:, 0:3]), np.ascontiguousarray(r[:, 3:6])
         self.mass, self.ids = np.ascontiguousarray(r[:, 6]), r[:, 7].astype(np.int64)
+        n_new = len(r)
         lo = self.pos.min(axis=0) if n_new else np.full(3, np.inf)
         hi = self.pos.max(axis=0) if n_new else np.full(3, -np.inf)
         self.bbox.copy_(torch.from_numpy(np.concatenate([lo, hi])))
