@@ -226,11 +226,20 @@ __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, c
 __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
                                                    const uint32_t *__restrict__ perm, int shift,
                                                    uint32_t *__restrict__ perm_out, uint64_t *__restrict__ hi_out, int64_t n,
-                                                   TreeInfo *info) {
+                                                   TreeInfo *info, const int32_t *__restrict__ dead_rank = nullptr,
+                                                   int64_t n_dead = 0) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const uint64_t h = hi_s[r], hp = h >> shift;
     const uint32_t p = perm[r];
+    if (dead_rank && h == ~0ull) {
+        // owner mode: the row of a body that has left (all-ones key, larger than any real one): the n_dead of them
+        // take the last n_dead places, in row order - no run to search, however many there are
+        const int64_t slot = n - n_dead + dead_rank[p];
+        perm_out[slot] = p;
+        hi_out[slot] = h;
+        return;
+    }
     const bool tie = (r + 1 < n && (hi_s[r + 1] >> shift) == hp) || (r > 0 && (hi_s[r - 1] >> shift) == hp);
     if (!tie) {
         perm_out[r] = p;
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
         if ((hi_s[mid] >> shift) == hp) hi_ok = mid; else hi_bad = mid;
     }
     const int64_t s = lo_ok, e = hi_bad;
-    if (r == s && e - s > 64) atomicMax(&info->max_run, (int)(e - s < 0x7fffffff ? e - s : 0x7fffffff));
+    if (r == s && e - s > 64 && !(dead_rank && hi_s[e - 1] == ~0ull)) atomicMax(&info->max_run, (int)(e - s < 0x7fffffff ? e - s : 0x7fffffff));
     const uint64_t la = key_lo[p];
     int64_t before = 0;
     for (int64_t j = s; j < e; j++) {
@@ -1406,6 +1415,10 @@ __global__ __launch_bounds__(kBlock) void k_dest(const uint64_t *__restrict__ ke
     idx[i] = (uint32_t)i;
 }
 
+__global__ __launch_bounds__(kBlock) void k_dead_flags(const uint8_t *__restrict__ dead, int64_t n, int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) flag[i] = dead[i] ? 1 : 0;
+}
 // owner mode, migration: flag row j of destination d = 1 if body i goes to rank d (d != me); dead[i] = leaves
 __global__ __launch_bounds__(kBlock) void k_emigrant_flags(const uint32_t *__restrict__ dest, int64_t n, int world, int me,
                                                            int64_t stride, int32_t *__restrict__ flag, uint8_t *__restrict__ dead) {
@@ -1894,7 +1907,8 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     const int shift = 63 - s->sort_bits;
     NBMI_HIP_CHECK(nbmi::sort_pairs_u64_u32(s->tmp_sort, s->tmp_sort_bytes, s->key_hi, s->hi_s, s->idx, s->perm,
                                             (size_t)n, shift, 63, st));
-    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, shift, s->idx, s->key_hi, n, s->info);
+    k_tiefix<<<nblocks(n), kBlock, 0, st>>>(s->hi_s, s->key_lo, s->perm, shift, s->idx, s->key_hi, n, s->info,
+                                            dead ? s->let_scan : nullptr, n - n_live);
     // the finished permutation / sorted upper words are `perm` / `hi_s` from here on; the old buffers take
     // the next step's indices and keys
     std::swap(s->perm, s->idx);
@@ -2722,6 +2736,9 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
     if (n_new > 0) {
+        // rank of every dead row among the dead rows (exclusive scan of the flags): their place behind the live ones
+        k_dead_flags<<<nblocks(n_work), kBlock, 0, st>>>(s->let_dead, n_work, s->let_keep);
+        if (int rc = enqueue_iscan(s, s->let_keep, n_work, s->let_scan)) return rc;
         if (int rc = enqueue_local_sort(s, -1, n_work, n_new, s->let_dead)) return rc;
         if (int rc = enqueue_global_tree(s)) return rc;
         // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags).  The node count lives on
