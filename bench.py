@@ -375,8 +375,8 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
     par = "single GPU"
     if world > 1 or use_dist:
         par = {"rows": f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows",
-               "let": f"x{world}: key-range owners, body migration (all-to-all), per-rank octree, all-gather of "
-                      "locally essential cells",
+               "let": f"x{world}: key-range owners, body migration (all-to-all-v), per-rank octree in the global cube, "
+                      "all-to-all-v of locally essential trees",
                }.get(shard_mode, shard_mode) if method == "barnes_hut" else \
             f"x{world}: body-index shards of the all-pairs kernel, all-gather of 64-B rows"
     out = {
@@ -490,10 +490,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(dev)
         backend = os.environ.get("NBMI_BENCH_BACKEND", "nccl")  # "gloo": 1-GPU rehearsal of the N>1 path
+        import datetime
+        patience = datetime.timedelta(seconds=int(os.environ.get("NBMI_BENCH_TIMEOUT_S", "300")))  # a stuck rank ends the run
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev), timeout=patience)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
 
     method = WORKLOADS[args.workload][7]
