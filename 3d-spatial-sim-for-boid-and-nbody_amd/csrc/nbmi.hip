@@ -610,6 +610,32 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
 }
 
 // ---------------------------------------------------------------------------------------
+// K8b: child table.  Row i of an internal cell holds the byte offsets of its (up to 8) children in pre-order
+// (0 = no more children; offset 0 is the root and never a child).  The stack walk (k_walk_stack) expands a
+// cell with one 32-byte load of this row instead of following the sibling links one dependent load at a time.
+// One thread per internal cell, after all nodes exist: first child = next row, siblings via the skip links.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_child_table(const Node *__restrict__ nodes, const int32_t *__restrict__ Pex,
+                                                        const int32_t *__restrict__ cell_r, int64_t n, int64_t capacity,
+                                                        uint32_t *__restrict__ child_tab) {
+    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t ncells = Pex[n];
+    if (q >= ncells || n + ncells + 1 > capacity) return;
+    const int64_t idx = (int64_t)cell_r[q] + q;
+    const unsigned end = nodes[idx].next_off;
+    unsigned c = (unsigned)(idx + 1) * kNodeBytes;
+    uint32_t t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        t[k] = c < end ? c : 0u;
+        if (c < end) c = reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + c)->next_off;
+    }
+    uint4 *row = reinterpret_cast<uint4 *>(child_tab + 8 * idx);
+    row[0] = make_uint4(t[0], t[1], t[2], t[3]);
+    row[1] = make_uint4(t[4], t[5], t[6], t[7]);
+}
+
+// ---------------------------------------------------------------------------------------
 // K9: the walk.  One wave64 = 64 consecutive sorted bodies; wave-uniform cursor over the
 // pre-order node array (scalar loads of the 24-byte record); per lane the reference's test
 // (simulation.py:245-274):
@@ -1086,6 +1112,81 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     for (int k = 1; k < K; k++) {
         ax += part[k][0][lane]; ay += part[k][1][lane]; az += part[k][2][lane];
     }
+    integrate(tab, j, rank, ax, ay, az, P, frozen);
+}
+
+// ---------------------------------------------------------------------------------------
+// Stack walk (NBMI_WALK_STACK=1, prototype): the same 64 bodies per wave and the same per-lane opening test,
+// but the wave keeps a stack of (cell, mask of the lanes that opened it) and expands a cell by visiting all
+// its children back to back: their offsets come from ONE load of the child table, their records are requested
+// together, the lanes taking part are a scalar mask (no per-visit `resume` compare / update) and there is no
+// skip / descend decision per visit.  Accepted (body, node) sets are unchanged; sums associate differently.
+// ---------------------------------------------------------------------------------------
+constexpr int kStackCap = 320;  // > 7 pending siblings on each of the 43 possible levels
+__global__ __launch_bounds__(kBlock) void k_walk_stack(const Node *__restrict__ nodes, const uint32_t *__restrict__ child_tab,
+                                                       const WalkTable *tab, const TreeInfo *info_in,
+                                                       const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
+                                                       WalkParams P) {
+    __shared__ unsigned st_off[kBlock / 64][kStackCap];
+    __shared__ unsigned long long st_mask[kBlock / 64][kStackCap];
+    const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
+    const bool valid = rank < P.rank_end;
+    const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
+    const unsigned band2 = __builtin_amdgcn_readfirstlane(info_in->band2);
+    float px = 0.f, py = 0.f, pz = 0.f;
+    uint32_t j = 0;
+    if (valid) {
+        const float4 p = posm_s[rank];
+        px = p.x; py = p.y; pz = p.z;
+        j = perm[rank];
+    }
+    const Body64 b64{tab, P.curbuf, j};
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    int sp = 0;
+    const unsigned long long lane_bit = 1ull << lane;
+
+    // one node for the lanes in M: force for the lanes that take it, (offset, openers) pushed if anybody opens it
+    auto visit = [&](unsigned off, unsigned long long M) {
+        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
+        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
+        const bool in = (M & lane_bit) != 0ull;
+        const int d2b = __float_as_int(d2), hi = __float_as_int(nd.s2t), lo = hi - (int)band2;
+        bool geom = hi < d2b;
+        if (in && !geom && lo < d2b) geom = (hi == 0) || exact_take(off, b64);
+        const bool take = in && geom;
+        const float inv = __builtin_amdgcn_rsqf(d2);
+        const float f = take ? (nd.gm * inv) * (inv * inv) : 0.f;
+        ax = fmaf(dx, f, ax); ay = fmaf(dy, f, ay); az = fmaf(dz, f, az);
+        const unsigned long long openers = __builtin_amdgcn_ballot_w64(in && !geom);
+        if (openers && sp < kStackCap) {
+            if (lane == 0) { st_off[w][sp] = off; st_mask[w][sp] = openers; }
+            sp++;
+        }
+    };
+
+    if (!frozen) {
+        visit(0u, __builtin_amdgcn_ballot_w64(valid));
+        while (sp > 0) {
+            sp--;
+            const unsigned cell = __builtin_amdgcn_readfirstlane(st_off[w][sp]);
+            const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)st_mask[w][sp]);
+            const unsigned mhi = __builtin_amdgcn_readfirstlane((unsigned)(st_mask[w][sp] >> 32));
+            const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;
+            const uint4 *row = reinterpret_cast<const uint4 *>(child_tab + 8 * (size_t)(cell / kNodeBytes));
+            const uint4 t0 = row[0], t1 = row[1];
+            const unsigned ch[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned c = __builtin_amdgcn_readfirstlane(ch[k]);
+                if (c == 0u) break;
+                visit(c, M);
+            }
+        }
+    }
+    if (!valid) return;
     integrate(tab, j, rank, ax, ay, az, P, frozen);
 }
 
@@ -1769,6 +1870,7 @@ struct nbmi_sim {
     Moment *S = nullptr;
     ScanVal *tile_sum = nullptr;
     Node *nodes = nullptr;
+    uint32_t *child_tab = nullptr;  // 8 child offsets per node row (stack walk)
     Node64 *nodes64 = nullptr;  // float64 twin rows of the internal cells (near-tie re-decision)
     WalkTable *wtab = nullptr;  // device copy of the walk's per-handle constants
     uint8_t *node_level = nullptr;
@@ -1813,6 +1915,7 @@ struct nbmi_sim {
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
+    int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
@@ -1939,6 +2042,8 @@ int enqueue_global_tree(nbmi_sim *s) {
     k_emit_cells<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
                                                                   n, s->softening, inv_theta2, s->own_node_rows, s->nodes,
                                                                   s->nodes64, s->node_level, s->node_ref, s->info);
+    if (s->walk_stack)
+        k_child_table<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->nodes, s->Pex, s->cell_r, n, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1998,6 +2103,12 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     }
     const int wb = s->walk_block;
     const int gb = (int)((cntr + wb - 1) / wb);
+    if (integrate && s->walk_stack && !guard && !s->owner) {
+        k_walk_stack<<<(int)((cntr + kBlock - 1) / kBlock), kBlock, 0, st>>>(s->nodes, s->child_tab, s->wtab, s->info, s->posm_s,
+                                                                             s->perm, P);
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (integrate && s->walk_lane) {  // measurement only, see k_walk_lane
         k_walk_lane<<<gb, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P);
         NBMI_HIP_CHECK(hipGetLastError());
@@ -2106,6 +2217,7 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
+    if (const char *e = getenv("NBMI_WALK_STACK")) s->walk_stack = atoi(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {
         const int b = atoi(e);
         if (b >= 8 && b <= 63) s->sort_bits = b;
@@ -2140,6 +2252,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->tile_sum, (c + 1) / kScanTile + 2) ||
             dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
+            (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
             dev_alloc(s, &s->cell_r, own_rows - c) || dev_alloc(s, &s->cell_lev, own_rows - c))
             return -2;
         s->own_node_rows = own_rows;
