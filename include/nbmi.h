@@ -144,7 +144,8 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * prune their trees against this rank's bounding boxes with the reference's own opening test, made conservative
  * by 1e-9).  Per-rank sort / build / memory no longer grow with the number of ranks.  Cells that straddle a
  * rank boundary are seen as one partial cell per rank instead of one whole cell, so positions agree with
- * the single-GPU run to a tolerance (measured 1e-9 relative after 5 steps at 100 k bodies), not bit for bit;
+ * the single-GPU run to a tolerance (measured 1.1e-7 of the largest coordinate after 5 steps at 60 k bodies on
+ * three ranks; the tests bound it by 1e-6), not bit for bit;
  * the replicated-tree exchange above (nbmi_set_shard) stays as the bit-exact mode.
  *
  * One step, host side (buffers are DEVICE pointers; the collectives are the host framework's):
@@ -158,7 +159,9 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *        all-to-all of the counts, all-to-all-v of the rows  (only bodies that crossed a splitter travel)
  *   nbmi_owner_adopt(h, recv, n_recv, m, box)       the n_recv received rows join the bodies that stayed: keys, sort, octree;
  *                                                   box <- B = nbmi_owner_boxes_per_rank() bounding boxes (6 doubles
- *                                                   each: lo xyz, hi xyz), one per equal chunk of the key order
+ *                                                   each: lo xyz, hi xyz) of the bodies inside cells of the own
+ *                                                   tree (level 4, refined to level 11 along the two boundary
+ *                                                   chains), in key order; unused boxes are empty (lo > hi)
  *        all-gather of the boxes                    (world x B x 6 doubles)
  *   nbmi_owner_export_let(h, boxes, let, counts)    prune the own tree against EACH other rank's boxes: counts[j] rows
  *                                                   for rank j, packed one destination after the other in `let`
