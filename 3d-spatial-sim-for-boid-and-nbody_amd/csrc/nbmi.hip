@@ -1461,7 +1461,7 @@ namespace {
 // appending of locally essential trees.  The collectives themselves are the host framework's (RCCL).
 // =========================================================================================
 constexpr int kMaxWorld = 64;
-constexpr int kSampleCap = 4096;  // world x samples_per_rank, sorted in LDS by one workgroup
+constexpr int kSampleCap = 4096;  // world x samples_per_rank, ranked in LDS
 
 // regular samples of the (nearly key-ordered) local keys
 __global__ __launch_bounds__(kBlock) void k_key_samples(const uint64_t *__restrict__ key_hi, int64_t n, int nsamples,
@@ -1472,35 +1472,40 @@ __global__ __launch_bounds__(kBlock) void k_key_samples(const uint64_t *__restri
     out[k] = n > 0 ? key_hi[(int64_t)((2 * (int64_t)k + 1) * n / (2 * (int64_t)nsamples))] : ~0ull;
 }
 
-// one workgroup: bitonic sort of all ranks' samples in LDS, then world - 1 splitters at equal quantiles of the
-// valid samples.  Rank j owns the keys in [split[j-1], split[j]).
+// world - 1 splitters at equal quantiles of the valid samples: every sample finds its rank among all of them by
+// counting (all samples in LDS, broadcast reads), and the ones whose rank is a quantile write themselves.
+// Rank j owns the keys in [split[j-1], split[j]).  Any number of workgroups (one sample per thread).
 __global__ __launch_bounds__(kBlock) void k_splitters(const uint64_t *__restrict__ samples, int total, int world,
                                                       uint64_t *__restrict__ split) {
     __shared__ uint64_t a[kSampleCap];
-    for (int i = threadIdx.x; i < kSampleCap; i += kBlock) a[i] = i < total ? samples[i] : ~0ull;
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
     __syncthreads();
-    for (int k = 2; k <= kSampleCap; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < kSampleCap; i += kBlock) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint64_t x = a[i], y = a[l];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { a[i] = y; a[l] = x; }
-                }
-            }
-            __syncthreads();
-        }
+    int cnt = 0;
+    for (int i = threadIdx.x; i < total; i += kBlock) {
+        const uint64_t v = samples[i];
+        a[i] = v;
+        cnt += v != ~0ull ? 1 : 0;
     }
-    __shared__ int valid;
-    if (threadIdx.x == 0) {
-        int lo = 0, hi = total;  // first all-ones entry
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] == ~0ull) hi = mid; else lo = mid + 1; }
-        valid = lo;
-    }
+    if (cnt) atomicAdd(&s_valid, cnt);
     __syncthreads();
-    for (int j = threadIdx.x; j < world - 1; j += kBlock)
-        split[j] = valid > 0 ? a[(int)((int64_t)(j + 1) * valid / world)] : ~0ull;
+    const int valid = s_valid;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (valid == 0) {
+        if (i < world - 1) split[i] = ~0ull;
+        return;
+    }
+    if (i >= total) return;
+    const uint64_t x = a[i];
+    if (x == ~0ull) return;
+    int rank = 0;
+#pragma unroll 16
+    for (int j = 0; j < total; j++) {
+        const uint64_t y = a[j];
+        rank += (y < x || (y == x && j < i)) ? 1 : 0;
+    }
+    for (int j = 0; j < world - 1; j++)
+        if ((int)((int64_t)(j + 1) * valid / world) == rank) split[j] = x;
 }
 
 // destination rank of every body: number of splitters <= its upper key word (bodies that agree on all 21
@@ -1553,6 +1558,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_emigrants(Bodies cur, const uin
 // are neighbours in space and get a common "super box" for a two-level test.
 constexpr int kBoxLevel = 4, kBoxLevelMax = 11;
 constexpr int kBoxesPerRank = 2048, kSuper = 32, kSupersPerRank = kBoxesPerRank / kSuper;
+constexpr int kMegasPerRank = 8, kSupersPerMega = kSupersPerRank / kMegasPerRank;
 
 // flag[i] = 1 if node i is one of the cells / leaves whose bodies get a box
 __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
@@ -1602,33 +1608,49 @@ __global__ __launch_bounds__(kBlock) void k_box_ranges(const Node *__restrict__ 
     ranges[2 * k + 1] = (k == kBoxesPerRank - 1 && slot[rows] > kBoxesPerRank) ? (int32_t)n
                                                                                     : (int32_t)(nx < num_nodes ? node_ref[nx] : n);
 }
-// one workgroup per box: tight bounding box of the bodies [a, b) (empty box: lo = +inf > hi = -inf)
+// tight bounding boxes of the bodies of every range (empty box: lo = +inf > hi = -inf).  The ranges are
+// consecutive in key order and very unequal (a level-4 cell of a galaxy core holds 10^5 bodies, a refined
+// boundary cell a handful), so the work is cut by BODIES: a wave takes kBoxChunk consecutive bodies, finds the
+// ranges that overlap them and adds its part of each with float64 atomic min / max.
+constexpr int kBoxChunk = 1024;
+__global__ void k_boxes_init(double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * kBoxesPerRank) out[i] = (i % 6) < 3 ? INFINITY : -INFINITY;
+}
 __global__ __launch_bounds__(kBlock) void k_range_boxes(const double4 *__restrict__ p64_s, const int32_t *__restrict__ ranges,
-                                                        const int32_t *__restrict__ total, double *__restrict__ out) {
-    __shared__ double red[6][kBlock / 64];
-    const int k = blockIdx.x;
-    const int64_t b0 = k < *total && k < kBoxesPerRank ? ranges[2 * k] : 0, b1 = k < *total && k < kBoxesPerRank ? ranges[2 * k + 1] : 0;
-    double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = b0 + threadIdx.x; i < b1; i += kBlock) {
-        const double4 q = p64_s[i];
-        v[0] = fmin(v[0], q.x); v[1] = fmin(v[1], q.y); v[2] = fmin(v[2], q.z);
-        v[3] = fmax(v[3], q.x); v[4] = fmax(v[4], q.y); v[5] = fmax(v[5], q.z);
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double t = __shfl_xor(v[c], o);
-            v[c] = c < 3 ? fmin(v[c], t) : fmax(v[c], t);
+                                                        const int32_t *__restrict__ total, int64_t n, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int64_t c0 = wave * kBoxChunk, c1 = c0 + kBoxChunk < n ? c0 + kBoxChunk : n;
+    if (c0 >= n) return;
+    const int nb = *total < kBoxesPerRank ? *total : kBoxesPerRank;
+    int lo = 0, hi = nb;  // first range that ends behind c0
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)ranges[2 * mid + 1] > c0) hi = mid; else lo = mid + 1; }
+    for (int k = lo; k < nb; k++) {
+        const int64_t r0 = ranges[2 * k], r1 = ranges[2 * k + 1];
+        if (r0 >= c1) break;
+        const int64_t a = r0 > c0 ? r0 : c0, b = r1 < c1 ? r1 : c1;
+        double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int64_t i = a + lane; i < b; i += 64) {
+            const double4 q = p64_s[i];
+            v[0] = fmin(v[0], q.x); v[1] = fmin(v[1], q.y); v[2] = fmin(v[2], q.z);
+            v[3] = fmax(v[3], q.x); v[4] = fmax(v[4], q.y); v[5] = fmax(v[5], q.z);
         }
-        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v[c];
-    }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        const int c = threadIdx.x;
-        double r = red[c][0];
-        for (int w = 1; w < kBlock / 64; w++) r = c < 3 ? fmin(r, red[c][w]) : fmax(r, red[c][w]);
-        out[6 * k + c] = r;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double t = __shfl_xor(v[c], o);
+                v[c] = c < 3 ? fmin(v[c], t) : fmax(v[c], t);
+            }
+        }
+        if (lane < 6 && a < b) {
+            double r = v[0];
+#pragma unroll
+            for (int c = 1; c < 6; c++) r = lane == c ? v[c] : r;
+            if (lane < 3) atomicMin(&out[6 * k + lane], r);
+            else atomicMax(&out[6 * k + lane], r);
+        }
     }
 }
 // super box = union of kSuper consecutive boxes (of every rank)
@@ -1738,12 +1760,14 @@ __device__ __forceinline__ bool box_may_open(const double *__restrict__ b, const
     return (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9) <= thr;  // some point of the box may fail "size / dist < theta"
 }
 // one pass over the own tree decides for EVERY destination rank: diff row j marks the pre-order ranges rank j
-// does not need.  Three-level test per destination: the union box of the rank, its super boxes, its boxes.
+// does not need.  Four-level test per destination: the union box of the rank, its mega boxes, super boxes, boxes.
 __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
                                                      int64_t num_nodes, const double *__restrict__ boxes,
-                                                     const double *__restrict__ supers, const double *__restrict__ rankbox,
-                                                     int world, int me, double theta, double eps2,
+                                                     const double *__restrict__ supers, const double *__restrict__ megas,
+                                                     const double *__restrict__ rankbox, int world, int me, double theta, double eps2,
                                                      int32_t *__restrict__ diff, int64_t stride) {
+    // (a wave-uniform form of these loops - a level entered if ANY lane needs it, box data by scalar loads -
+    // was slower, 266 vs 190 us at 8 ranks: the lanes' early exits are worth more than the cheaper loads)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= num_nodes) return;
     const Node nd = nodes[i];
@@ -1758,9 +1782,12 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
         if (j == me) continue;
         bool needed = all;
         if (!needed && box_may_open(rankbox + 6 * j, c, eps2, thr)) {
-            for (int sb = j * kSupersPerRank; sb < (j + 1) * kSupersPerRank && !needed; sb++) {
-                if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
-                for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
+            for (int g = j * kMegasPerRank; g < (j + 1) * kMegasPerRank && !needed; g++) {
+                if (!box_may_open(megas + 6 * g, c, eps2, thr)) continue;
+                for (int sb = g * kSupersPerMega; sb < (g + 1) * kSupersPerMega && !needed; sb++) {
+                    if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
+                    for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
+                }
             }
         }
         if (!needed) {
@@ -1812,17 +1839,27 @@ __global__ void k_let_counts(const int32_t *__restrict__ newidx, int64_t num_nod
         off += c;
     }
 }
-// union box of each rank's super boxes
-__global__ void k_rank_boxes(const double *__restrict__ supers, int world, double *__restrict__ rankbox) {
-    const int j = threadIdx.x;
-    if (j >= world) return;
+// two more levels above the super boxes: kMegasPerRank "mega boxes" (kSupersPerMega consecutive super boxes each)
+// and the union box of the rank.  One workgroup, one thread per mega box.
+__global__ __launch_bounds__(kMaxWorld * kMegasPerRank) void k_rank_boxes(const double *__restrict__ supers, int world,
+                                                                          double *__restrict__ megas, double *__restrict__ rankbox) {
+    __shared__ double m[kMaxWorld * kMegasPerRank][6];
+    const int t = threadIdx.x, j = t / kMegasPerRank;
     double v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int k = 0; k < kSupersPerRank; k++) {
-        const double *b = supers + 6 * (j * kSupersPerRank + k);
-        if (!(b[0] <= b[3])) continue;
-        for (int c = 0; c < 3; c++) { v[c] = fmin(v[c], b[c]); v[3 + c] = fmax(v[3 + c], b[3 + c]); }
+    if (j < world) {
+        for (int k = 0; k < kSupersPerMega; k++) {
+            const double *b = supers + 6 * ((int64_t)t * kSupersPerMega + k);
+            if (!(b[0] <= b[3])) continue;
+            for (int c = 0; c < 3; c++) { v[c] = fmin(v[c], b[c]); v[3 + c] = fmax(v[3 + c], b[3 + c]); }
+        }
+        for (int c = 0; c < 6; c++) { megas[6 * t + c] = v[c]; m[t][c] = v[c]; }
     }
-    for (int c = 0; c < 6; c++) rankbox[6 * j + c] = v[c];
+    __syncthreads();
+    if (j < world && t % kMegasPerRank == 0) {
+        for (int g = 1; g < kMegasPerRank; g++)
+            for (int c = 0; c < 3; c++) { v[c] = fmin(v[c], m[t + g][c]); v[3 + c] = fmax(v[3 + c], m[t + g][3 + c]); }
+        for (int c = 0; c < 6; c++) rankbox[6 * j + c] = v[c];
+    }
 }
 // a received tree goes behind the trees already in the walk array: links shift by the base
 __global__ __launch_bounds__(kBlock) void k_let_append(const char *__restrict__ src, int64_t count, int64_t base,
@@ -1903,7 +1940,7 @@ struct nbmi_sim {
     uint32_t *let_dest = nullptr;
     int64_t *let_counts = nullptr;
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
-    double *let_supers = nullptr, *let_rankbox = nullptr;
+    double *let_supers = nullptr, *let_megas = nullptr, *let_rankbox = nullptr;
     int64_t let_stride = 0, let_tile_stride = 0;  // rows between two destinations' work arrays
     // frame codec: previous decoded frame (positions then colours, float32, caller's order) and the int16 payload
     float *frame_prev = nullptr;
@@ -2739,7 +2776,8 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
             dev_alloc(s, &s->let_counts, 2 * kMaxWorld) || dev_alloc(s, &s->let_dead, c) ||
             dev_alloc(s, &s->let_diff, all) || dev_alloc(s, &s->let_scan, all) || dev_alloc(s, &s->let_keep, all) ||
             dev_alloc(s, &s->let_tiles, (size_t)s->let_tile_stride * world) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
-            dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
+            dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) ||
+            dev_alloc(s, &s->let_megas, (size_t)6 * kMegasPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
             rc = -2;
     }
     if (rc == 0 && n > 0) {  // global ids instead of the row numbers k_split_state wrote
@@ -2808,7 +2846,7 @@ int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_sam
     const int64_t n = s->n, stride = s->let_stride;
     const int W = s->world;
     for (int j = 0; j < W; j++) counts[j] = 0;
-    k_splitters<<<1, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, W, s->let_split);
+    k_splitters<<<(total_samples + kBlock - 1) / kBlock, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, W, s->let_split);
     if (n > 0) {
         // only the bodies whose key has left this rank's range travel; everybody else stays where it is
         k_dest<<<nblocks(n), kBlock, 0, st>>>(s->key_hi, n, s->let_split, W, s->let_dest, s->idx);
@@ -2861,7 +2899,9 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
         if (int rc = enqueue_iscan(s, s->let_keep, rows, s->let_scan)) return rc;
         NBMI_HIP_CHECK(hipMemsetAsync(s->let_ranges, 0, sizeof(int32_t) * 2 * kBoxesPerRank, st));
         k_box_ranges<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, s->info, rows, n_new, s->let_ranges);
-        k_range_boxes<<<kBoxesPerRank, kBlock, 0, st>>>(s->p64_s, s->let_ranges, s->let_scan + rows, (double *)dev_boxes);
+        k_boxes_init<<<(6 * kBoxesPerRank + kBlock - 1) / kBlock, kBlock, 0, st>>>((double *)dev_boxes);
+        k_range_boxes<<<(unsigned)((n_new + (int64_t)kBoxChunk * (kBlock / 64) - 1) / ((int64_t)kBoxChunk * (kBlock / 64))), kBlock, 0, st>>>(
+            s->p64_s, s->let_ranges, s->let_scan + rows, n_new, (double *)dev_boxes);
     } else {
         std::vector<double> empty(6 * kBoxesPerRank);
         for (int k = 0; k < 6 * kBoxesPerRank; k++) empty[k] = (k % 6) < 3 ? INFINITY : -INFINITY;
@@ -2888,8 +2928,8 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int
     const int W = s->world;
     NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)stride * W * 4, st));
     k_super_boxes<<<(W * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, W * kSupersPerRank, s->let_supers);
-    k_rank_boxes<<<1, kMaxWorld, 0, st>>>(s->let_supers, W, s->let_rankbox);
-    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_rankbox, W,
+    k_rank_boxes<<<1, kMaxWorld * kMegasPerRank, 0, st>>>(s->let_supers, W, s->let_megas, s->let_rankbox);
+    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_megas, s->let_rankbox, W,
                                               s->rank, s->theta, s->softening * s->softening, s->let_diff, stride);
     if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
     k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep);
