@@ -679,6 +679,7 @@ struct WalkParams {
 struct WalkTable {
     Bodies buf[2];
     const Node64 *n64;
+    const int32_t *pex;  // leaf of the body at sorted rank r = node r + pex[r + 1]
     double theta, eps2;
 };
 
@@ -995,8 +996,19 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
 
     if (!kCount && !kGuard) {
         if (nn && P.pair) {
-            // two cursors: [0, mid) and [mid, nn); the second needs the lanes' state at mid (seek)
-            const unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->walk_nodes / 2) * kNodeBytes);
+            // two cursors: [0, mid) and [mid, nn); the second needs the lanes' state at mid (seek).
+            // Where to cut: a wave spends ~40 % of its visits inside the 1/64 of the array around its own bodies
+            // (scripts/analysis/range_balance.py), so equal halves keep both cursors busy for only a fifth of the
+            // visits; cutting at the leaf of the wave's middle body does for two thirds of them.
+            unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->walk_nodes / 2) * kNodeBytes);
+            if (P.pair == 2) {
+                const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                const int64_t r0 = P.rank_begin + (int64_t)lb * blockDim.x + wv * 64;
+                const int64_t rl = r0 + 64 < P.rank_end ? r0 + 64 : P.rank_end;  // the wave's bodies: [r0, rl)
+                const int64_t rm = r0 < rl ? r0 + (rl - r0) / 2 : 0;
+                const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + tab->pex[rm + 1]) * kNodeBytes);
+                mid = (r0 < rl && home > 0u && home < nn) ? home : mid;
+            }
             // (each half sums into its own accumulator, added at the end: a body's result must not depend
             // on how the two cursors' visits interleave, i.e. on the other bodies of its group)
             unsigned resume2 = resume;
@@ -1891,6 +1903,12 @@ __global__ void k_copy_ids(const int32_t *__restrict__ ids, int32_t *__restrict_
 // =========================================================================================
 // handle
 // =========================================================================================
+// Measured (MI355X, theta 0.5): cutting at the wave's own leaves keeps both cursors busy for 68 % of the visits
+// instead of 21 %, yet at 1 M bodies (galaxy) the walk is 2 % slower with it (1.194 vs 1.172 ms) and at 10 M
+// (collision) 6 % faster (10.80 vs 11.53 ms): what two cursors overlap is the latency of the far-field jumps,
+// and only once the node array is far beyond the L2 does pairing a far-field cursor with a near-field one pay.
+constexpr int64_t kHomeSplitBodies = 4000000;
+
 struct nbmi_sim {
     int64_t n = 0;
     int method = 0, device = 0;
@@ -1954,7 +1972,10 @@ struct nbmi_sim {
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
     int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
-    int walk_pair = 1;  // two cursors per wave in the one-wave walk; NBMI_WALK_PAIR=0 switches it off
+    // one-wave walk: cursors per wave and where the array is cut.  -1 = by size: two cursors, cut at the middle of the
+    // array, or (from kHomeSplitBodies bodies on) at the leaf of the wave's middle body; NBMI_WALK_PAIR = 0 / 1 / 2 forces
+    // one cursor / the middle cut / the home cut
+    int walk_pair = -1;
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)
     // timers
     bool timers = false;
@@ -1988,6 +2009,7 @@ int upload_walk_table(nbmi_sim *s) {
     t.buf[0] = s->buf[0];
     t.buf[1] = s->buf[1];
     t.n64 = s->nodes64;
+    t.pex = s->Pex;
     t.theta = s->theta;
     t.eps2 = s->softening * s->softening;
     NBMI_HIP_CHECK(hipMemcpyAsync(s->wtab, &t, sizeof(t), hipMemcpyHostToDevice, s->stream));
@@ -2117,7 +2139,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     const int64_t cntr = P.rank_end - P.rank_begin;
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
-    P.pair = s->walk_pair;
+    P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
     P.curbuf = s->curbuf;
 
     // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on

@@ -36,8 +36,12 @@ ROW = 8  # doubles per packed body row (include/nbmi.h nbmi_export_shard)
 
 
 def shard_bounds(n: int, world: int, rank: int):
-    """Equal-count contiguous ranges of sorted ranks; `per` is the padded all-gather chunk."""
+    """Equal-count contiguous ranges of sorted ranks; `per` is the padded all-gather chunk.  A range starts at a
+    multiple of 64 ranks: a wave's 64 bodies are then the same ones however the ranks are sharded, and so is the
+    place where the walk cuts the node array between its two cursors (large systems cut at the wave's own
+    leaves) - the condition for results that do not depend on the sharding bit for bit."""
     per = (n + world - 1) // world
+    per = (per + 63) // 64 * 64
     begin = min(n, rank * per)
     end = min(n, begin + per)
     return per, begin, end

@@ -1,14 +1,14 @@
 #!/bin/bash
-# four-cursor walk (NBMI_WALK_PAIR=4) vs the two-cursor default: parity tests with it, then alternating bench runs
+# a walk variant selected by NBMI_WALK_PAIR (2 = two cursors cut at the wave's own leaves) vs the default: parity tests with it, then alternating bench runs
 set -u
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/quad
 mkdir -p $O
 cd $R
-NBMI_WALK_PAIR=4 timeout -k 10 900 python -m pytest tests/test_gpu_nbody.py -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; echo "pytest(quad) rc=$rc"; tail -4 $O/pytest.log
+NBMI_WALK_PAIR=2 timeout -k 10 900 python -m pytest tests/test_gpu_nbody.py -x -q -m gpu > $O/pytest.log 2>&1; rc=$?; echo "pytest(home split) rc=$rc"; tail -4 $O/pytest.log
 [ $rc -ne 0 ] && exit $rc
 for rep in 1 2; do
-  for mode in 1 4; do
+  for mode in 1 2; do
     NBMI_WALK_PAIR=$mode timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_${rep}_$mode.json 2> $O/err.txt || { echo "bench failed"; tail -5 $O/err.txt; exit 1; }
     python3 - "$O/bench_${rep}_$mode.json" "$mode" <<'PY'
 import json, sys

@@ -7,11 +7,17 @@ from conftest import golden
 pytestmark = pytest.mark.gpu
 
 
-def test_virtual_shards_bit_identical_to_single_handle(gpu):
+@pytest.mark.parametrize("knobs", [{}, {"NBMI_SPLIT_WAVES": "0"}, {"NBMI_SPLIT_WAVES": "0", "NBMI_WALK_PAIR": "2"}],
+                         ids=["split-walk", "one-wave-walk", "one-wave-walk-home-cut"])
+def test_virtual_shards_bit_identical_to_single_handle(gpu, monkeypatch, knobs):
     """Three handles on one GPU play three ranks: each integrates its key-range, rows are exchanged
     through device buffers exactly as nbody/sharded.py does (the all-gather itself replaced by
-    torch.cat).  The result must equal the unsharded handle bit for bit."""
+    torch.cat).  The result must equal the unsharded handle bit for bit - with every walk form: the split walk
+    this size gets by default, the one-wave walk, and the one-wave walk that cuts the node array at the wave's
+    own leaves (the default from 4 M bodies on; shard ranges start at multiples of 64 ranks for its sake)."""
     import torch
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     from nbody.gpu_backend import HIPBarnesHutSimulation
     from nbody.sharded import HipShardEngine, ShardedBarnesHut, shard_bounds
     g = golden("tree_collision_2048")
