@@ -1009,8 +1009,9 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                 const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + tab->pex[rm + 1]) * kNodeBytes);
                 mid = (r0 < rl && home > 0u && home < nn) ? home : mid;
             }
-            // (each half sums into its own accumulator, added at the end: a body's result must not depend
-            // on how the two cursors' visits interleave, i.e. on the other bodies of its group)
+            // (each half sums into its own accumulator, added at the end: a body's result does not depend on how the two
+            // cursors' visits interleave.  With the home cut it does depend on which 64 ranks form the wave - the same
+            // ones for every sharding whose ranges start at multiples of 64 ranks)
             unsigned resume2 = resume;
             float bx = 0.f, by = 0.f, bz = 0.f;
             unsigned o1 = 0u, o2 = __builtin_amdgcn_readfirstlane(mid ? seek(C, P, mid, resume2) : 0u);
@@ -1903,11 +1904,13 @@ __global__ void k_copy_ids(const int32_t *__restrict__ ids, int32_t *__restrict_
 // =========================================================================================
 // handle
 // =========================================================================================
-// Measured (MI355X, theta 0.5): cutting at the wave's own leaves keeps both cursors busy for 68 % of the visits
-// instead of 21 %, yet at 1 M bodies (galaxy) the walk is 2 % slower with it (1.194 vs 1.172 ms) and at 10 M
-// (collision) 6 % faster (10.80 vs 11.53 ms): what two cursors overlap is the latency of the far-field jumps,
-// and only once the node array is far beyond the L2 does pairing a far-field cursor with a near-field one pay.
-constexpr int64_t kHomeSplitBodies = 4000000;
+// Measured (MI355X, theta 0.5, walk ms, middle cut -> cut at the wave's own leaves): galaxy 1 M 1.251 -> 1.251, 2 M
+// 2.515 -> 2.409, 4 M 5.13 -> 4.95, 10 M 12.85 -> 12.28; collision 1 M 1.402 -> 1.389, 2 M 2.477 -> 2.386, 4 M
+// 4.68 -> 4.40, 10 M 11.50 -> 10.79.  The home cut keeps both cursors busy for 68-81 % of the visits instead of
+// ~20 % (scripts/analysis/range_balance.py), but what two cursors overlap is the latency of far-field jumps, and
+// that only shows once the node array is far beyond the L2.  (A cut placed by a two-component model of where the
+// visits are - 75 % instead of 68 % at 1 M - measured the same or slower.)
+constexpr int64_t kHomeSplitBodies = 1500000;
 
 struct nbmi_sim {
     int64_t n = 0;
@@ -1973,7 +1976,7 @@ struct nbmi_sim {
     int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     // one-wave walk: cursors per wave and where the array is cut.  -1 = by size: two cursors, cut at the middle of the
-    // array, or (from kHomeSplitBodies bodies on) at the leaf of the wave's middle body; NBMI_WALK_PAIR = 0 / 1 / 2 forces
+    // array, or (from kHomeSplitBodies = 1.5 M bodies on) at the leaf of the wave's middle body; NBMI_WALK_PAIR = 0 / 1 / 2 forces
     // one cursor / the middle cut / the home cut
     int walk_pair = -1;
     int64_t split_max_waves = 9400;  // split walk: K waves per group while groups x K fits; NBMI_SPLIT_WAVES (0 = off)

@@ -14,7 +14,7 @@ def test_virtual_shards_bit_identical_to_single_handle(gpu, monkeypatch, knobs):
     through device buffers exactly as nbody/sharded.py does (the all-gather itself replaced by
     torch.cat).  The result must equal the unsharded handle bit for bit - with every walk form: the split walk
     this size gets by default, the one-wave walk, and the one-wave walk that cuts the node array at the wave's
-    own leaves (the default from 4 M bodies on; shard ranges start at multiples of 64 ranks for its sake)."""
+    own leaves (the default from 1.5 M bodies on; shard ranges start at multiples of 64 ranks for its sake)."""
     import torch
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
