@@ -212,6 +212,75 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
     // order inside a cell is unspecified anyway: np.argsort, flock.py:618).
     const int x_lo = cx - g.range < 0 ? 0 : cx - g.range;
     const int x_hi = cx + g.range > g.dim - 1 ? g.dim - 1 : cx + g.range;
+    // one candidate: the reference's test and sums (flock.py:134-172)
+    auto candidate = [&](int32_t q) {
+        if (q == r) return;
+        const double4 qp = b.p[q];
+        const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
+        const double dist_sq = dx * dx + dy * dy + dz * dz;
+        if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
+            const double dist = sqrt(dist_sq);
+            if (dist_sq < P.separation_sq) {
+                const double inv_dist = 1.0 / dist;
+                sx += dx * inv_dist / dist;
+                sy += dy * inv_dist / dist;
+                sz += dz * inv_dist / dist;
+                sep_count++;
+            }
+            const double4 qv = b.v[q], qc = b.c[q];
+            alx += qv.x; aly += qv.y; alz += qv.z;
+            cox += qp.x; coy += qp.y; coz += qp.z;
+            clr += qc.x; clg += qc.y; clb += qc.z;
+            nb_count++;
+        }
+    };
+    if (g.range == 1) {
+        // The usual grid (cell = perception radius, flock.py:478-481).  A row of cells is 3 cells = at most two
+        // words of the occupancy table, and what a row costs is a chain of dependent loads (table word -> run
+        // bounds -> candidates), not arithmetic: the three rows of a z plane go through each stage TOGETHER, so
+        // that their loads are in flight at the same time.  Same rows, same order, same sums as the loop below.
+        for (int dcz = -1; dcz <= 1; dcz++) {
+            const int ncz = cz + dcz;
+            const bool zok = ncz >= 0 && ncz < g.dim;
+            uint2 wa[3], wb[3];
+            int lo_bit[3], hi_bit[3];
+            bool two[3], rok[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int ncy = cy + j - 1;
+                rok[j] = zok && ncy >= 0 && ncy < g.dim;
+                const int64_t row = (int64_t)ncy * g.dim + (int64_t)ncz * g.dim * g.dim;
+                const int64_t c_lo = row + x_lo, c_hi = row + x_hi;
+                lo_bit[j] = (int)(c_lo & 31);
+                hi_bit[j] = (int)(c_hi & 31);
+                two[j] = (c_lo >> 5) != (c_hi >> 5);
+                wa[j] = rok[j] ? occ[c_lo >> 5] : make_uint2(0u, 0u);
+                wb[j] = (rok[j] && two[j]) ? occ[c_hi >> 5] : make_uint2(0u, 0u);
+            }
+            int32_t qb[3], qe[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                uint32_t ba = wa[j].x & (~0u << lo_bit[j]);
+                uint32_t bb = wb[j].x & (~0u >> (31 - hi_bit[j]));
+                if (!two[j]) { ba &= ~0u >> (31 - hi_bit[j]); bb = 0u; }
+                qb[j] = 0; qe[j] = 0;
+                if (rok[j] && (ba | bb)) {
+                    // first and last non-empty cell of the row
+                    const uint2 fw = ba ? wa[j] : wb[j];
+                    const int first = ba ? __ffs(ba) - 1 : __ffs(bb) - 1;
+                    const uint2 lw = bb ? wb[j] : wa[j];
+                    const int last = bb ? 31 - __clz(bb) : 31 - __clz(ba);
+                    const uint32_t k_lo = fw.y + __popc(fw.x & ((1u << first) - 1u));
+                    const uint32_t k_hi = lw.y + __popc(lw.x & ((1u << last) - 1u)) + 1u;
+                    qb[j] = cell_start[k_lo];
+                    qe[j] = cell_start[k_hi];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                for (int32_t q = qb[j]; q < qe[j]; q++) candidate(q);
+        }
+    } else {
     for (int dcz = -g.range; dcz <= g.range; dcz++) {
         const int ncz = cz + dcz;
         if (ncz < 0 || ncz >= g.dim) continue;
@@ -238,28 +307,9 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
             const uint32_t k_lo = first_w.y + __popc(first_w.x & ((1u << first) - 1u));
             const uint32_t k_hi = last_w.y + __popc(last_w.x & ((1u << last) - 1u)) + 1u;
             const int32_t q_begin = cell_start[k_lo], q_end = cell_start[k_hi];
-            for (int32_t q = q_begin; q < q_end; q++) {
-                if (q == r) continue;
-                const double4 qp = b.p[q];
-                const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
-                const double dist_sq = dx * dx + dy * dy + dz * dz;
-                if (dist_sq < P.perception_sq && dist_sq > 0.0001) {
-                    const double dist = sqrt(dist_sq);
-                    if (dist_sq < P.separation_sq) {
-                        const double inv_dist = 1.0 / dist;
-                        sx += dx * inv_dist / dist;
-                        sy += dy * inv_dist / dist;
-                        sz += dz * inv_dist / dist;
-                        sep_count++;
-                    }
-                    const double4 qv = b.v[q], qc = b.c[q];
-                    alx += qv.x; aly += qv.y; alz += qv.z;
-                    cox += qp.x; coy += qp.y; coz += qp.z;
-                    clr += qc.x; clg += qc.y; clb += qc.z;
-                    nb_count++;
-                }
-            }
+            for (int32_t q = q_begin; q < q_end; q++) candidate(q);
         }
+    }
     }
     double fsx = 0, fsy = 0, fsz = 0, fax = 0, fay = 0, faz = 0, fcx = 0, fcy = 0, fcz = 0;
     double avr = cir, avg = cig, avb = cib;  // caller pre-fill: avg_colors <- colors (flock.py:636)
