@@ -18,3 +18,4 @@ done
 N=1000000 STEPS=100 OMP_NUM_THREADS=32 timeout -k 10 900 python scripts/gpu_parity_1m.py > $O/r02_parity_galaxy_1m_100steps.jsonl 2> $O/parity.err; echo "parity rc=$?"
 tail -2 $O/r02_parity_galaxy_1m_100steps.jsonl
 timeout -k 10 500 python scripts/gpu_let_probe.py 1000000 1,2,4,8 2> $O/let_probe.err > $O/r02_owner_mode_probe.jsonl; echo "probe rc=$?"
+PROBE_SCALE_RADIUS=0 timeout -k 10 300 python scripts/gpu_let_probe.py 1000000 8 2> $O/let_probe_dense.err > $O/r02_owner_mode_probe_bench_radius.jsonl; echo "probe (bench radius) rc=$?"
