@@ -99,6 +99,8 @@ struct TreeInfo {
     int error;                       // 1 = node capacity exceeded
     int max_run;                     // longest run of bodies equal in the radix-sorted key prefix (> 64 only)
     int pad0;
+    unsigned long long maxabs_next;  // max |coordinate| of the positions this step's integrating walk WRITES: the next
+                                     // step's maxabs_bits without a pass over the bodies (k_header)
     unsigned long long wave_visits, lane_visits, lane_accepts;
     unsigned long long win_miss[4];  // counted walk: node-window misses for windows of 8/16/32/64 nodes
     unsigned long long jumps;        // cursor moves other than to the next node in memory
@@ -166,6 +168,21 @@ __global__ __launch_bounds__(kBlock) void k_maxabs(const double *__restrict__ x,
         for (int w = 1; w < kBlock / 64; w++) mx = fmax(mx, red[w]);
         atomicMax(&info->maxabs_bits, (unsigned long long)__double_as_longlong(mx));
     }
+}
+
+// The step's tree header when the previous step's integrating walk has already left max |coordinate| of the
+// positions it wrote in maxabs_next: take it over and clear the rest (instead of a memset + a pass over the bodies).
+__global__ void k_header(TreeInfo *info) {
+    if (threadIdx.x != 0) return;
+    info->maxabs_bits = info->maxabs_next;
+    info->maxabs_next = 0ull;
+    info->bounds = 0.0;
+    info->num_nodes = 0;
+    info->walk_nodes = 0;
+    info->max_level = 0;
+    info->error = 0;
+    info->max_run = 0;
+    info->pad0 = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -680,6 +697,7 @@ struct WalkTable {
     Bodies buf[2];
     const Node64 *n64;
     const int32_t *pex;  // leaf of the body at sorted rank r = node r + pex[r + 1]
+    unsigned long long *maxabs_next;  // TreeInfo::maxabs_next
     double theta, eps2;
 };
 
@@ -948,8 +966,8 @@ __device__ __forceinline__ unsigned seek(const WalkCtx &C, const WalkParams &P, 
 
 // fused kick-drift (simulation.py:291-305) of the body at sorted rank `rank`, written at that rank of the
 // other buffer; frozen (a capacity error is pending): the body moves to its rank unchanged
-__device__ __forceinline__ void integrate(const WalkTable *tab, uint32_t j, int64_t rank, float ax,
-                                          float ay, float az, const WalkParams &P, bool frozen) {
+__device__ __forceinline__ double integrate(const WalkTable *tab, uint32_t j, int64_t rank, float ax,
+                                            float ay, float az, const WalkParams &P, bool frozen) {
     const Bodies cur = tab->buf[P.curbuf], nxt = tab->buf[1 - P.curbuf];
     double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
     double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j];
@@ -964,6 +982,18 @@ __device__ __forceinline__ void integrate(const WalkTable *tab, uint32_t j, int6
     nxt.x[rank] = x0; nxt.y[rank] = y0; nxt.z[rank] = z0;
     nxt.m[rank] = m0;
     nxt.id[rank] = id0;
+    return fmax(fmax(fabs(x0), fabs(y0)), fabs(z0));
+}
+
+// The largest |coordinate| a wave has just written joins TreeInfo::maxabs_next (all lanes of the wave call this;
+// lanes without a body pass 0).  Most waves find a value at least as large already there and skip the atomic.
+__device__ __forceinline__ void publish_maxabs(const WalkTable *tab, double lane_max) {
+    const double m = wave_max(lane_max);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        unsigned long long *dst = tab->maxabs_next;
+        if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
+    }
 }
 
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
@@ -1063,10 +1093,9 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
             if (bd) atomicAdd(&info_out->band_visits, bd);
         }
     }
-    if (!valid) return;
     if (kIntegrate) {
-        integrate(tab, j, rank, ax, ay, az, P, frozen);
-    } else {
+        publish_maxabs(tab, valid ? integrate(tab, j, rank, ax, ay, az, P, frozen) : 0.0);
+    } else if (valid) {
         const int64_t o = 3 * (int64_t)tab->buf[P.curbuf].id[j];
         acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
     }
@@ -1119,13 +1148,13 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     }
     part[w][0][lane] = ax; part[w][1][lane] = ay; part[w][2][lane] = az;
     __syncthreads();
-    if (w != 0 || !valid) return;
+    if (w != 0) return;
     ax = part[0][0][lane]; ay = part[0][1][lane]; az = part[0][2][lane];
 #pragma unroll
     for (int k = 1; k < K; k++) {
         ax += part[k][0][lane]; ay += part[k][1][lane]; az += part[k][2][lane];
     }
-    integrate(tab, j, rank, ax, ay, az, P, frozen);
+    publish_maxabs(tab, valid ? integrate(tab, j, rank, ax, ay, az, P, frozen) : 0.0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1973,6 +2002,9 @@ struct nbmi_sim {
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
+    bool maxabs_fused = false;  // TreeInfo::maxabs_next holds max |coordinate| of the CURRENT positions (set by a full
+                                // integrating walk, dropped by anything else that writes positions); NBMI_FUSE_MAXABS=0: never
+    bool fuse_maxabs = true;
     int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     // one-wave walk: cursors per wave and where the array is cut.  -1 = by size: two cursors, cut at the middle of the
@@ -2013,6 +2045,7 @@ int upload_walk_table(nbmi_sim *s) {
     t.buf[1] = s->buf[1];
     t.n64 = s->nodes64;
     t.pex = s->Pex;
+    t.maxabs_next = &s->info->maxabs_next;
     t.theta = s->theta;
     t.eps2 = s->softening * s->softening;
     NBMI_HIP_CHECK(hipMemcpyAsync(s->wtab, &t, sizeof(t), hipMemcpyHostToDevice, s->stream));
@@ -2041,6 +2074,12 @@ int enqueue_maxabs(nbmi_sim *s) {
     const int64_t n = s->n;
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf];
+    if (s->maxabs_fused) {  // the last walk left it behind (and nothing has touched the positions since)
+        s->maxabs_fused = false;
+        k_header<<<1, 64, 0, st>>>(s->info);
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     // reset maxabs/num_nodes/max_level/error (keep counters)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     int gb = nblocks(n);
@@ -2237,6 +2276,7 @@ int check_device_error(nbmi_sim *s) {
         NBMI_HIP_CHECK(hipMemsetAsync(&s->info->error, 0, sizeof(int), s->stream));
         NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
         s->tree_valid = false;
+        s->maxabs_fused = false;
     }
     if (h.error || h.sticky_error) {
         nbmi::set_error("octree needs %lld nodes, more than the %lld rows allocated (4N, as the reference); the "
@@ -2278,6 +2318,7 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
+    if (const char *e = getenv("NBMI_FUSE_MAXABS")) s->fuse_maxabs = atoi(e) != 0;
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
     if (const char *e = getenv("NBMI_WALK_STACK")) s->walk_stack = atoi(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {
@@ -2467,6 +2508,7 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
             // (sharded handles: the ranks outside [shard_begin, shard_end) arrive via nbmi_import_ranks)
             s->curbuf ^= 1;
             s->tree_valid = false;
+            s->maxabs_fused = s->fuse_maxabs && s->shard_begin == 0 && s->shard_end == s->n && !s->walk_stack && !s->walk_lane;
         } else {
             if (s->timers) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
             if (int rc = launch_direct<true>(s, dt, nullptr)) return rc;
@@ -2554,6 +2596,7 @@ int nbmi_set_state(nbmi_sim *s, const double *pos, const double *vel) {
     NBMI_HIP_CHECK(hipMemsetAsync(&s->info->sticky_error, 0, sizeof(int), s->stream));  // a fresh state: drop a pending capacity error
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->tree_valid = false;
+    s->maxabs_fused = false;
     return 0;
 }
 
@@ -2715,6 +2758,7 @@ int nbmi_set_shard(nbmi_sim *s, int64_t begin, int64_t end) {
     }
     s->shard_begin = begin;
     s->shard_end = end;
+    s->maxabs_fused = false;
     return 0;
 }
 
@@ -2738,6 +2782,7 @@ int nbmi_import_ranks(nbmi_sim *s, const void *dev_rows, int64_t begin, int64_t 
     k_unpack_rows<<<nblocks(c), kBlock, 0, s->stream>>>(s->buf[s->curbuf], begin, end, (const double *)dev_rows);
     NBMI_HIP_CHECK(hipGetLastError());
     if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->maxabs_fused = false;
     s->tree_valid = false;
     return 0;
 }
