@@ -304,34 +304,35 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// K5: gather bodies into key order: fp32 {x,y,z,G*m} (walk / leaf data), the same in float64 (input of
-// the moment prefix sums) and the low key word.
+// K5 + K6: gather bodies into key order - fp32 {x,y,z,G*m} (walk / leaf data), the same in float64 (input of
+// the moment prefix sums), the low key word - and, from the sorted keys of the two neighbours,
+//   delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1);
+//   cnt[r]   = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]).
+// (A neighbour's low key word is only fetched when the upper words agree: 21 common digits, rare.)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_gather(Bodies cur, const uint32_t *__restrict__ perm,
-                                                   const uint64_t *__restrict__ key_lo, int64_t n, double G,
-                                                   float4 *__restrict__ posm_s, double4 *__restrict__ p64_s,
-                                                   uint64_t *__restrict__ lo_s) {
+                                                   const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
+                                                   int64_t n, double G, float4 *__restrict__ posm_s,
+                                                   double4 *__restrict__ p64_s, uint64_t *__restrict__ lo_s,
+                                                   int32_t *__restrict__ delta, int32_t *__restrict__ cnt) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (r == 0) cnt[n] = 0;
     if (r >= n) return;
     const uint32_t j = perm[r];
     const double x = cur.x[j], y = cur.y[j], z = cur.z[j], gm = G * cur.m[j];
     posm_s[r] = make_float4((float)x, (float)y, (float)z, (float)gm);
     p64_s[r] = make_double4(x, y, z, gm);  // float64 twin: input of the moment sums (coalesced there)
-    lo_s[r] = key_lo[j];
-}
-
-// ---------------------------------------------------------------------------------------
-// K6: delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1);
-// cnt[r] = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_delta(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
-                                                  int64_t n, int32_t *__restrict__ delta, int32_t *__restrict__ cnt) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r == 0) cnt[n] = 0;
-    if (r >= n) return;
-    const uint64_t h = hi_s[r], l = lo_s[r];
-    const int d = (r + 1 < n) ? cpl_digits(h, l, hi_s[r + 1], lo_s[r + 1]) : -1;
-    const int dp = (r > 0) ? cpl_digits(hi_s[r - 1], lo_s[r - 1], h, l) : -1;
+    const uint64_t h = hi_s[r], l = key_lo[j];
+    lo_s[r] = l;
+    int d = -1, dp = -1;
+    if (r + 1 < n) {
+        const uint64_t hn = hi_s[r + 1];
+        d = cpl_digits(h, l, hn, hn == h ? key_lo[perm[r + 1]] : 0ull);
+    }
+    if (r > 0) {
+        const uint64_t hp = hi_s[r - 1];
+        dp = cpl_digits(hp, hp == h ? key_lo[perm[r - 1]] : 0ull, h, l);
+    }
     delta[r] = d;
     cnt[r] = d > dp ? d - dp : 0;
 }
@@ -2119,14 +2120,15 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     std::swap(s->hi_s, s->key_hi);
     s->t_hi = s->hi_s;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
-    k_gather<<<nblocks(n_live), kBlock, 0, st>>>(cur, s->perm, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s);
+    k_gather<<<nblocks(n_live), kBlock, 0, st>>>(cur, s->perm, s->hi_s, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s,
+                                                 s->delta, s->cnt);
     return 0;
 }
 
 int enqueue_global_tree(nbmi_sim *s) {
     const int64_t n = s->nt;
     hipStream_t st = s->stream;
-    k_delta<<<nblocks(n), kBlock, 0, st>>>(s->t_hi, s->t_lo, n, s->delta, s->cnt);
+    // (delta / cnt of the n bodies: written by k_gather)
     {
         const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
         // moments from the float64 state through the sort permutation; run exchange: from the fp32 records
