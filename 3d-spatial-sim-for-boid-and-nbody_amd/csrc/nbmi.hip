@@ -36,6 +36,7 @@
 
 #include "../../include/nbmi.h"
 #include "common.h"
+#include "hilbert.h"
 #include "visible.h"
 
 namespace nbmi {
@@ -190,10 +191,27 @@ __global__ void k_header(TreeInfo *info) {
 // root cube [-bounds, bounds]^3: digit = x>=cx | (y>=cy)<<1 | (z>=cz)<<2, centre +- hs/2.
 // Only compares, adds and exact halvings: bit-identical to the float64 reference.
 // ---------------------------------------------------------------------------------------
+// [r2] The digits are then RELABELLED along the 3-D Hilbert curve (hilbert.h: digit and next orientation from the
+// octant and the cell's orientation, a 24-state machine carried down the 42 levels).  Which bodies share a
+// level-L cell - every common-prefix length, hence the cell set, the node count, every cell's bodies - is
+// untouched; what changes is the order of a cell's eight children in the sorted array, and with it which 64
+// bodies share a wave: waves along the Hilbert curve are more compact and visit 7 % fewer nodes (1 M galaxy;
+// 5 % at the 10 M collision; scripts/analysis/hilbert_groups.py).  nbmi_get_keys / nbmi_get_cells decode back
+// to the reference's octant digits.  kHilbert = false (NBMI_HILBERT=0): plain octant digits.
+template <bool kHilbert>
 __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, const double *__restrict__ y,
                                                  const double *__restrict__ z, int64_t n, TreeInfo *info,
                                                  uint64_t *__restrict__ key_hi, uint64_t *__restrict__ key_lo,
                                                  uint32_t *__restrict__ idx, const uint8_t *__restrict__ dead = nullptr) {
+    __shared__ uint32_t hd[nbmi::kHilStates];
+    __shared__ uint64_t hn[nbmi::kHilStates];
+    if (kHilbert) {
+        if (threadIdx.x < nbmi::kHilStates) {
+            hd[threadIdx.x] = nbmi::kHilDigit[threadIdx.x];
+            hn[threadIdx.x] = nbmi::kHilNext[threadIdx.x];
+        }
+        __syncthreads();
+    }
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     // bounds = max_extent * 1.1 + 10.0 with two roundings (no FMA contraction)
     const double maxabs = __longlong_as_double((long long)info->maxabs_bits);
@@ -209,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, c
     const double px = x[i], py = y[i], pz = z[i];
     double cx = 0.0, cy = 0.0, cz = 0.0, hs = bounds;
     uint64_t k[2];
+    unsigned st = 0u;  // orientation of the current cell (root: 0)
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         uint64_t kk = 0;
@@ -219,7 +238,13 @@ __global__ __launch_bounds__(kBlock) void k_keys(const double *__restrict__ x, c
             cy = by ? cy + q : cy - q;
             cz = bz ? cz + q : cz - q;
             hs = q;
-            kk = (kk << 3) | (uint64_t)((bx ? 1 : 0) | (by ? 2 : 0) | (bz ? 4 : 0));
+            const unsigned oct = (bx ? 1u : 0u) | (by ? 2u : 0u) | (bz ? 4u : 0u);
+            if (kHilbert) {
+                kk = (kk << 3) | (uint64_t)((hd[st] >> (3u * oct)) & 7u);
+                st = (unsigned)(hn[st] >> (5u * oct)) & 31u;
+            } else {
+                kk = (kk << 3) | (uint64_t)oct;
+            }
         }
         k[w] = kk;
     }
@@ -1448,14 +1473,31 @@ __global__ __launch_bounds__(kBlock) void k_set_state_perm(const double *__restr
     cur.x[r] = pos[3 * i]; cur.y[r] = pos[3 * i + 1]; cur.z[r] = pos[3 * i + 2];
     cur.vx[r] = vel[3 * i]; cur.vy[r] = vel[3 * i + 1]; cur.vz[r] = vel[3 * i + 2];
 }
+// the reference's octant digits back from the sort key: `levels` digits of (hi, lo) decoded (hilbert.h), the rest 0
+__device__ __forceinline__ void octant_digits(uint64_t hi, uint64_t lo, int levels, uint64_t &ohi, uint64_t &olo) {
+    unsigned st = 0u;
+    ohi = 0ull; olo = 0ull;
+    for (int l = 0; l < levels; l++) {
+        const uint64_t w = l < 21 ? hi : lo;
+        const unsigned d = (unsigned)(w >> (3 * (20 - (l < 21 ? l : l - 21)))) & 7u;
+        const unsigned oct = (nbmi::kHilOctant[st] >> (3u * d)) & 7u;
+        st = (unsigned)(nbmi::kHilNextByDigit[st] >> (5u * d)) & 31u;
+        if (l < 21) ohi |= (uint64_t)oct << (3 * (20 - l));
+        else olo |= (uint64_t)oct << (3 * (41 - l));
+    }
+}
+// keys in the caller's body order; decode: as the reference's octant-path digits, else the raw sort keys
 __global__ __launch_bounds__(kBlock) void k_keys_to_orig(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
                                                          const uint32_t *__restrict__ perm, const int32_t *__restrict__ id,
-                                                         int64_t n, uint64_t *__restrict__ out_hi, uint64_t *__restrict__ out_lo) {
+                                                         int64_t n, int decode, uint64_t *__restrict__ out_hi,
+                                                         uint64_t *__restrict__ out_lo) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r >= n) return;
     const int64_t o = id[perm[r]];
-    out_hi[o] = hi_s[r];
-    out_lo[o] = lo_s[r];
+    uint64_t h = hi_s[r], l = lo_s[r];
+    if (decode) octant_digits(h, l, kMaxLevel, h, l);
+    out_hi[o] = h;
+    out_lo[o] = l;
 }
 __global__ __launch_bounds__(kBlock) void k_order(const uint32_t *__restrict__ perm, const int32_t *__restrict__ id,
                                                   int64_t n, int32_t *__restrict__ out) {
@@ -1464,14 +1506,16 @@ __global__ __launch_bounds__(kBlock) void k_order(const uint32_t *__restrict__ p
 }
 
 __global__ __launch_bounds__(kBlock) void k_cells(const int32_t *__restrict__ node_ref, const uint8_t *__restrict__ node_level,
-                                                  const uint64_t *__restrict__ hi_s, int64_t num_nodes,
+                                                  const uint64_t *__restrict__ hi_s, int64_t num_nodes, int decode,
                                                   int32_t *__restrict__ level, uint64_t *__restrict__ key) {
     const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (u >= num_nodes) return;
     const int r = node_ref[u];  // first body of the node's range
     const int lev = node_level[u];
     level[u] = lev;
-    key[u] = lev <= 21 ? (lev == 0 ? 0ull : (hi_s[r] >> (63 - 3 * lev))) : ~0ull;
+    uint64_t h = hi_s[r], l = 0ull;
+    if (decode && lev <= 21) octant_digits(h, 0ull, lev, h, l);  // the cell's path in the reference's octant digits
+    key[u] = lev <= 21 ? (lev == 0 ? 0ull : (h >> (63 - 3 * lev))) : ~0ull;
 }
 // multi-GPU row pack / unpack: {x,y,z,vx,vy,vz,m,id}
 __global__ __launch_bounds__(kBlock) void k_pack_rows(Bodies cur, int64_t begin, int64_t end, double *__restrict__ rows) {
@@ -2006,6 +2050,7 @@ struct nbmi_sim {
     bool maxabs_fused = false;  // TreeInfo::maxabs_next holds max |coordinate| of the CURRENT positions (set by a full
                                 // integrating walk, dropped by anything else that writes positions); NBMI_FUSE_MAXABS=0: never
     bool fuse_maxabs = true;
+    bool hilbert = true;  // sort keys relabelled along the Hilbert curve (k_keys); NBMI_HILBERT=0: plain octant digits
     int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
     // one-wave walk: cursors per wave and where the array is cut.  -1 = by size: two cursors, cut at the middle of the
@@ -2096,7 +2141,8 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     if (n_live < 0) n_live = n;
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf];
-    k_keys<<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx, dead);
+    if (s->hilbert) k_keys<true><<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx, dead);
+    else k_keys<false><<<nblocks(n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info, s->key_hi, s->key_lo, s->idx, dead);
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[1], st));
     // radix sort on the top sort_bits bits of the upper word, then the tie-fix completes the 126-bit order
     if (s->sort_bits == 0) {
@@ -2321,6 +2367,7 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
     if (const char *e = getenv("NBMI_FUSE_MAXABS")) s->fuse_maxabs = atoi(e) != 0;
+    if (const char *e = getenv("NBMI_HILBERT")) s->hilbert = atoi(e) != 0;
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
     if (const char *e = getenv("NBMI_WALK_STACK")) s->walk_stack = atoi(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {
@@ -2667,7 +2714,24 @@ int nbmi_get_keys(nbmi_sim *s, uint64_t *key_hi, uint64_t *key_lo) {
     const int64_t n = s->n;
     if (n == 0) return 0;
     uint64_t *o_hi = (uint64_t *)s->stage, *o_lo = o_hi + n;
-    k_keys_to_orig<<<nblocks(n), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->perm, s->buf[s->curbuf].id, n, o_hi, o_lo);
+    k_keys_to_orig<<<nblocks(n), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->perm, s->buf[s->curbuf].id, n, s->hilbert ? 1 : 0, o_hi, o_lo);
+    NBMI_HIP_CHECK(hipGetLastError());
+    if (key_hi) NBMI_HIP_CHECK(hipMemcpyAsync(key_hi, o_hi, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    if (key_lo) NBMI_HIP_CHECK(hipMemcpyAsync(key_lo, o_lo, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int nbmi_get_sort_keys(nbmi_sim *s, uint64_t *key_hi, uint64_t *key_lo) {
+    if (int rc = check_handle(s)) return rc;
+    if (s->method != NBMI_METHOD_BARNES_HUT || !s->tree_valid) {
+        nbmi::set_error("nbmi_get_sort_keys: call nbmi_build_tree first");
+        return NBMI_ERR_ARG;
+    }
+    const int64_t n = s->n;
+    if (n == 0) return 0;
+    uint64_t *o_hi = (uint64_t *)s->stage, *o_lo = o_hi + n;
+    k_keys_to_orig<<<nblocks(n), kBlock, 0, s->stream>>>(s->hi_s, s->lo_s, s->perm, s->buf[s->curbuf].id, n, 0, o_hi, o_lo);
     NBMI_HIP_CHECK(hipGetLastError());
     if (key_hi) NBMI_HIP_CHECK(hipMemcpyAsync(key_hi, o_hi, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
     if (key_lo) NBMI_HIP_CHECK(hipMemcpyAsync(key_lo, o_lo, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
@@ -2708,7 +2772,7 @@ int nbmi_get_cells(nbmi_sim *s, int32_t *level, uint64_t *key, int64_t capacity)
     uint64_t *dk = nullptr;
     NBMI_HIP_CHECK(hipMalloc((void **)&dl, (size_t)nn * 4));
     NBMI_HIP_CHECK(hipMalloc((void **)&dk, (size_t)nn * 8));
-    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->node_ref, s->node_level, s->t_hi, nn, dl, dk);
+    k_cells<<<nblocks(nn), kBlock, 0, s->stream>>>(s->node_ref, s->node_level, s->t_hi, nn, s->hilbert ? 1 : 0, dl, dk);
     hipError_t e1 = hipMemcpyAsync(level, dl, (size_t)nn * 4, hipMemcpyDeviceToHost, s->stream);
     hipError_t e2 = hipMemcpyAsync(key, dk, (size_t)nn * 8, hipMemcpyDeviceToHost, s->stream);
     hipError_t e3 = hipStreamSynchronize(s->stream);
@@ -2900,7 +2964,8 @@ int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, in
     hipStream_t st = s->stream;
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
     Bodies cur = s->buf[s->curbuf];
-    if (s->n > 0) k_keys<<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
+    if (s->n > 0 && s->hilbert) k_keys<true><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
+    else if (s->n > 0) k_keys<false><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
     k_key_samples<<<(nsamples + kBlock - 1) / kBlock, kBlock, 0, st>>>(s->key_hi, s->n, nsamples, (uint64_t *)dev_samples);
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipStreamSynchronize(st));

@@ -37,6 +37,7 @@ PROTOTYPES = {
     "nbmi_get_accelerations_f64": (C.c_int, [_vp, _vp]),
     "nbmi_tree_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
     "nbmi_get_keys": (C.c_int, [_vp, _vp, _vp]),
+    "nbmi_get_sort_keys": (C.c_int, [_vp, _vp, _vp]),
     "nbmi_get_cells": (C.c_int, [_vp, _vp, _vp, _i64]),
     "nbmi_enable_timers": (C.c_int, [_vp, C.c_int]),
     "nbmi_get_timers": (C.c_int, [_vp, _vp, _vp, C.c_int]),

@@ -284,6 +284,13 @@ class HIPBarnesHutSimulation(_HIPSimulation):
         _nat.check(self._lib.nbmi_get_keys(self._h, _nat.ptr(hi), _nat.ptr(lo)), "nbmi_get_keys")
         return hi, lo
 
+    def sort_keys(self):
+        """The keys the device sorts by (octant digits relabelled along the Hilbert curve), caller's order."""
+        hi = np.empty(self.n, dtype=np.uint64)
+        lo = np.empty(self.n, dtype=np.uint64)
+        _nat.check(self._lib.nbmi_get_sort_keys(self._h, _nat.ptr(hi), _nat.ptr(lo)), "nbmi_get_sort_keys")
+        return hi, lo
+
     def cells(self):
         """(level, key) of every node of the last built tree."""
         nn = self.tree_stats()["num_nodes"]

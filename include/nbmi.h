@@ -108,8 +108,13 @@ int nbmi_tree_stats(nbmi_sim *sim, int64_t *num_nodes, int32_t *max_depth, doubl
  * key_hi = levels 1..21 (3 bits per level, level 1 most significant, digit =
  * x>=cx | (y>=cy)<<1 | (z>=cz)<<2 as get_octant, simulation.py:38-49), key_lo = levels 22..42. */
 int nbmi_get_keys(nbmi_sim *sim, uint64_t *key_hi, uint64_t *key_lo);
-/* Body indices in octant-key (octree DFS) order for the most recently built tree: order[r] = index,
- * in the caller's numbering, of the r-th body along the key order. */
+/* The keys the device actually sorts by, same layout: the octant digits relabelled along the 3-D Hilbert curve
+ * (csrc/hilbert.h: the digit of a child depends on its octant and on the orientation of its cell; a bijection per
+ * cell, so two bodies share exactly as many leading digits as with the octant digits, and nbmi_get_keys is the
+ * decoded form of these).  Only the order of a cell's eight children differs from the octant order. */
+int nbmi_get_sort_keys(nbmi_sim *sim, uint64_t *key_hi, uint64_t *key_lo);
+/* Body indices in sort-key (octree DFS, children along the Hilbert curve) order for the most recently built tree:
+ * order[r] = index, in the caller's numbering, of the r-th body along that order. */
 int nbmi_get_order(nbmi_sim *sim, int32_t *order);
 /* (level, path key) of every node of the most recently built tree (num_nodes entries,
  * unspecified order).  Keys of levels > 21 are reported as UINT64_MAX. */

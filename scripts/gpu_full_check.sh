@@ -10,13 +10,13 @@ timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; rc=
 [ $rc -ne 0 ] && exit $rc
 fi
 for rep in 1 2; do
-  for fuse in 1 0; do
-    NBMI_FUSE_MAXABS=$fuse timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
-    python3 - "$O/bench.json" "$fuse" <<'PY'
+  for hil in 1 0; do
+    NBMI_HILBERT=$hil timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err || { echo "bench failed"; tail -5 $O/bench.err; exit 1; }
+    python3 - "$O/bench.json" "$hil" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 t = d.get("north_star_10m") or {}
-print("fuse", sys.argv[2], "1M", round(d["ms_per_step"], 4), {k: round(v, 4) for k, v in d["phase_ms"].items()}, "10M", round(t.get("ms_per_step", 0), 3), {k: round(v, 3) for k, v in t.get("phase_ms", {}).items()})
+print("hilbert", sys.argv[2], "1M", round(d["ms_per_step"], 4), {k: round(v, 4) for k, v in d["phase_ms"].items()}, "10M", round(t.get("ms_per_step", 0), 3), {k: round(v, 3) for k, v in t.get("phase_ms", {}).items()})
 PY
   done
 done

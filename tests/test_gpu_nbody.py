@@ -45,6 +45,12 @@ def test_tree_bit_exact(gpu, oracle, name):
     hi, lo = sim.morton_keys()
     ohi, olo = oracle.body_keys(pos, st["bounds"])
     assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
+    # ... which the device keeps relabelled along the Hilbert curve: the raw sort keys equal the test-side mirror
+    from hilbert_ref import hilbert_keys
+    shi, slo = sim.sort_keys()
+    ehi, elo = hilbert_keys(ohi, olo)
+    assert np.array_equal(shi, ehi) and np.array_equal(slo, elo)
+    assert np.array_equal(sim.key_order(), np.lexsort((np.arange(len(pos)), elo, ehi)).astype(np.int32))
     ll = g["leaf_level"].astype(np.uint64)
     assert np.array_equal(hi >> (np.uint64(63) - np.uint64(3) * ll), g["leaf_key"])
     level, key = sim.cells()
@@ -256,8 +262,13 @@ def test_long_run_of_equal_upper_key_words(gpu, oracle):
     sim.sync()
     t_build = time.perf_counter() - t0
     order = sim.key_order()
-    expect = np.lexsort((np.arange(n), olo, ohi)).astype(np.int32)
+    # the device sorts by the octant digits relabelled along the Hilbert curve (csrc/hilbert.h; mirror: hilbert_ref)
+    from hilbert_ref import hilbert_keys
+    shi, slo = hilbert_keys(ohi, olo)
+    expect = np.lexsort((np.arange(n), slo, shi)).astype(np.int32)
     assert np.array_equal(order, expect)
+    dhi, dlo = sim.sort_keys()
+    assert np.array_equal(dhi, shi) and np.array_equal(dlo, slo)
     hi, lo = sim.morton_keys()
     assert np.array_equal(hi, ohi) and np.array_equal(lo, olo)
     nd = oracle.NodeArrays(4 * n + 4096)
