@@ -307,7 +307,8 @@ class HIPBarnesHutSimulation(_HIPSimulation):
                     xcd_visits=[int(v) for v in out[8:16]], band_visits=int(out[16]))
 
     def key_order(self):
-        """Body indices along the octant-key order of the last built tree."""
+        """Body indices along the sort-key order of the last built tree (octree DFS, the eight children of a cell
+        in Hilbert-curve order; see sort_keys)."""
         out = np.empty(self.n, dtype=np.int32)
         _nat.check(self._lib.nbmi_get_order(self._h, _nat.ptr(out)), "nbmi_get_order")
         return out

@@ -1,4 +1,5 @@
-"""Multi-GPU Barnes-Hut: one process per GPU, bodies sharded by octant-key range.
+"""Multi-GPU Barnes-Hut: one process per GPU, bodies sharded by key range (octant-path keys, children of a cell
+ordered along the Hilbert curve: a range of the key order is a compact piece of space).
 
 The reference is single-device; this is new design, in two forms:
 
