@@ -713,6 +713,7 @@ struct WalkParams {
     int pair;       // one-wave walk with two cursors (the two halves of the array)
     double dt, damping;
     int curbuf;  // which of WalkTable.buf holds the current state
+    int acc64;   // measurement (counted walk only, NBMI_ACC64=1): every visit's contribution summed in float64
 };
 
 // Per-handle constants the walk needs only rarely (float64 re-decision) or only at its end (the state
@@ -840,8 +841,32 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 #define NBMI_VISIT_2B \
     NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", "8f")
 // leaving the loop on a near-tie: all lanes back on, tell the caller which cursor stopped
-#define NBMI_EXITS                      \
+// Two-level sums: the loops add into fp32 accumulators (one instruction per component and visit); every few
+// trips those are emptied into float64 sums (NBMI_FLUSH: convert, add, clear), so an fp32 running sum never grows
+// beyond a dozen terms.  Measured at 1 M bodies against the float64 oracle, per-body relative acceleration error:
+// fp32 running sums over the whole walk rms 5.4e-7 (median 4.1e-7), every contribution summed in float64 1.1e-7
+// (5.4e-8) - the running sums were four fifths of the error.  The flush blocks sit behind the loops (reached by a
+// branch once per NBMI_FLUSH_TRIPS trips).
+#define NBMI_FLUSH(AX, AY, AZ)                      \
+    "v_cvt_f64_f32_e32 %[t64], " AX "\n"            \
+    "v_add_f64 %[sx], %[sx], %[t64]\n"              \
+    "v_mov_b32_e32 " AX ", 0\n"                     \
+    "v_cvt_f64_f32_e32 %[t64], " AY "\n"            \
+    "v_add_f64 %[sy], %[sy], %[t64]\n"              \
+    "v_mov_b32_e32 " AY ", 0\n"                     \
+    "v_cvt_f64_f32_e32 %[t64], " AZ "\n"            \
+    "v_add_f64 %[sz], %[sz], %[t64]\n"              \
+    "v_mov_b32_e32 " AZ ", 0\n"
+// at the loop-back point: count the trip down; on underflow empty the accumulators (label 40, returns to 41)
+#define NBMI_TRIP_COUNT                 \
+    "s_sub_u32 %[cnt], %[cnt], 1\n"     \
+    "s_cbranch_scc1 40f\n"              \
+    "41:\n"
+#define NBMI_EXITS(FLUSHES, TRIPS)      \
     "s_branch 9f\n"                     \
+    "40:\n" FLUSHES                     \
+    "s_mov_b32 %[cnt], " TRIPS "\n"     \
+    "s_branch 41b\n"                    \
     "7:\n"                              \
     "s_mov_b64 exec, -1\n"              \
     "s_mov_b32 %[which], 1\n"           \
@@ -859,15 +884,19 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 // sentinel absorbs the overshoot) or a near-tie stops it (which = 1, cursor on the tied node)
 __device__ __forceinline__ void walk4_asm(const Node *nodes, unsigned &off, unsigned end, float px, float py, float pz,
                                           float eps2, unsigned band2, unsigned &resume, float &ax, float &ay, float &az,
-                                          unsigned &which) {
+                                          double &sx, double &sy, double &sz, unsigned &which) {
     float dx, dy, dz, d2, inv, f, t;
-    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+    double t64;
+    unsigned cnt;
+    asm volatile("s_mov_b32 %[cnt], 3\n"
+                 "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B
+                 "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 "s_cbranch_scc1 1b\n" NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "3")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
-                   [az] "+v"(az), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
+                   [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
                    [f] "=&v"(f), [t] "=&v"(t)
                  : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end),
                    [band2] "s"(band2)
@@ -877,17 +906,21 @@ __device__ __forceinline__ void walk4_asm(const Node *nodes, unsigned &off, unsi
 // one visit per loop test: a part must not step past its end (the next part starts there)
 __device__ __forceinline__ void walk1_asm(const Node *nodes, unsigned &off, unsigned end, float px, float py, float pz,
                                           float eps2, unsigned band2, unsigned &resume, float &ax, float &ay, float &az,
-                                          unsigned &which) {
+                                          double &sx, double &sy, double &sz, unsigned &which) {
     float dx, dy, dz, d2, inv, f, t;
-    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+    double t64;
+    unsigned cnt;
+    asm volatile("s_mov_b32 %[cnt], 7\n"
+                 "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "1:\n" NBMI_VISIT_A
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 "s_cbranch_scc1 1b\n" NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "7")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
-                   [az] "+v"(az), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
+                   [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
                    [f] "=&v"(f), [t] "=&v"(t)
                  : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end),
                    [band2] "s"(band2)
@@ -904,9 +937,13 @@ __device__ __forceinline__ void walk1_asm(const Node *nodes, unsigned &off, unsi
 __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1, unsigned end1, unsigned &off2,
                                               unsigned end2, float px, float py, float pz, float eps2, unsigned band2,
                                               unsigned &resume1, unsigned &resume2, float &ax, float &ay, float &az,
-                                              float &ax2, float &ay2, float &az2, unsigned &which) {
+                                              float &ax2, float &ay2, float &az2, double &sx, double &sy, double &sz,
+                                              unsigned &which) {
     float dx, dy, dz, d2, inv, f, t;
-    asm volatile("s_load_dwordx4 s[36:39], %[base], %[off]\n"
+    double t64;
+    unsigned cnt;
+    asm volatile("s_mov_b32 %[cnt], 3\n"
+                 "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
                  "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
@@ -914,12 +951,14 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc0 9f\n" NBMI_VISIT_1B NBMI_VISIT_2B
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n"
+                 "s_cbranch_scc0 9f\n" NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off2], %[end2]\n"
-                 "s_cbranch_scc1 1b\n" NBMI_EXITS
+                 "s_cbranch_scc1 1b\n"
+                 NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]") NBMI_FLUSH("%[ax2]", "%[ay2]", "%[az2]"), "3")
                  : [off] "+s"(off1), [off2] "+s"(off2), [which] "+s"(which), [resume] "+v"(resume1),
                    [resume2] "+v"(resume2), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2),
-                   [ay2] "+v"(ay2), [az2] "+v"(az2), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2),
+                   [ay2] "+v"(ay2), [az2] "+v"(az2), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64),
+                   [cnt] "=&s"(cnt), [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2),
                    [inv] "=&v"(inv), [f] "=&v"(f), [t] "=&v"(t)
                  : [base] "s"(nodes), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [end] "s"(end1),
                    [end2] "s"(end2), [band2] "s"(band2)
@@ -945,12 +984,13 @@ __device__ __forceinline__ unsigned tie_visit(const WalkCtx &C, const WalkParams
 // the cursor `off` walks until it reaches `end`; kToEnd: `end` is the end of the array (unrolled loop)
 template <bool kToEnd>
 __device__ __forceinline__ void walk_span(const WalkCtx &C, const WalkParams &P, unsigned off, unsigned end,
-                                          unsigned &resume, float &ax, float &ay, float &az) {
+                                          unsigned &resume, float &ax, float &ay, float &az, double &sx, double &sy,
+                                          double &sz) {
     off = __builtin_amdgcn_readfirstlane(off);
     while (off < end) {
         unsigned which = 0u;
-        if (kToEnd) walk4_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, which);
-        else walk1_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, which);
+        if (kToEnd) walk4_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, sx, sy, sz, which);
+        else walk1_asm(C.nodes, off, end, C.px, C.py, C.pz, P.eps2, C.band2, resume, ax, ay, az, sx, sy, sz, which);
         off = __builtin_amdgcn_readfirstlane(off);
         if (!__builtin_amdgcn_readfirstlane(which)) break;
         off = tie_visit(C, P, off, resume, ax, ay, az);
@@ -992,15 +1032,15 @@ __device__ __forceinline__ unsigned seek(const WalkCtx &C, const WalkParams &P, 
 
 // fused kick-drift (simulation.py:291-305) of the body at sorted rank `rank`, written at that rank of the
 // other buffer; frozen (a capacity error is pending): the body moves to its rank unchanged
-__device__ __forceinline__ double integrate(const WalkTable *tab, uint32_t j, int64_t rank, float ax,
-                                            float ay, float az, const WalkParams &P, bool frozen) {
+__device__ __forceinline__ double integrate(const WalkTable *tab, uint32_t j, int64_t rank, double ax,
+                                            double ay, double az, const WalkParams &P, bool frozen) {
     const Bodies cur = tab->buf[P.curbuf], nxt = tab->buf[1 - P.curbuf];
     double vx = cur.vx[j], vy = cur.vy[j], vz = cur.vz[j];
     double x0 = cur.x[j], y0 = cur.y[j], z0 = cur.z[j];
     const double m0 = cur.m[j];
     const int32_t id0 = cur.id[j];
     if (!frozen) {
-        vx += (double)ax * P.dt; vy += (double)ay * P.dt; vz += (double)az * P.dt;
+        vx += ax * P.dt; vy += ay * P.dt; vz += az * P.dt;
         vx *= P.damping; vy *= P.damping; vz *= P.damping;
         x0 += vx * P.dt; y0 += vy * P.dt; z0 += vz * P.dt;
     }
@@ -1048,7 +1088,9 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     }
     C.b64 = Body64{tab, P.curbuf, j};
     unsigned resume = valid ? 0u : 0xffffffffu;
-    float ax = 0.f, ay = 0.f, az = 0.f;
+    float ax = 0.f, ay = 0.f, az = 0.f;  // fp32 accumulators of the loops ...
+    double sx = 0.0, sy = 0.0, sz = 0.0;  // ... emptied into these every few trips (two-level sums, NBMI_FLUSH)
+    double acc64x = 0.0, acc64y = 0.0, acc64z = 0.0;
 
     if (!kCount && !kGuard) {
         if (nn && P.pair) {
@@ -1074,7 +1116,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
             while (mid && o1 < mid && o2 < nn) {
                 unsigned which = 0u;
                 walk_pair_asm(nodes, o1, mid, o2, nn, C.px, C.py, C.pz, P.eps2, C.band2, resume, resume2, ax, ay, az,
-                              bx, by, bz, which);
+                              bx, by, bz, sx, sy, sz, which);
                 o1 = __builtin_amdgcn_readfirstlane(o1);
                 o2 = __builtin_amdgcn_readfirstlane(o2);
                 which = __builtin_amdgcn_readfirstlane(which);
@@ -1082,21 +1124,28 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                 else if (which == 2u) o2 = tie_visit(C, P, o2, resume2, bx, by, bz);
                 else break;
             }
-            if (o1 < mid) walk_span<false>(C, P, o1, mid, resume, ax, ay, az);
-            if (o2 < nn && o2 >= mid) walk_span<true>(C, P, o2, nn, resume2, bx, by, bz);
-            ax += bx; ay += by; az += bz;
+            if (o1 < mid) walk_span<false>(C, P, o1, mid, resume, ax, ay, az, sx, sy, sz);
+            if (o2 < nn && o2 >= mid) walk_span<true>(C, P, o2, nn, resume2, bx, by, bz, sx, sy, sz);
+            sx += (double)bx; sy += (double)by; sz += (double)bz;
         } else if (nn) {
-            walk_span<true>(C, P, 0u, nn, resume, ax, ay, az);
+            walk_span<true>(C, P, 0u, nn, resume, ax, ay, az, sx, sy, sz);
         }
     } else {
         unsigned long long wv = 0, lv = 0, la = 0, jm = 0, bd = 0;
+        double dax = 0.0, day = 0.0, daz = 0.0;
         unsigned long long wm[4] = {0, 0, 0, 0};
         int wbase[4] = {-1000, -1000, -1000, -1000};
         unsigned off = 0u;
         while (off < nn) {
             bool a_, f_, j_, b_;
             const int c_old = (int)(off / kNodeBytes);
-            off = visit<kGuard>(nodes, off, C.px, C.py, C.pz, C.b64, P, C.band2, resume, ax, ay, az, a_, f_, j_, b_);
+            if (kCount && P.acc64) {
+                float tx = 0.f, ty = 0.f, tz = 0.f;
+                off = visit<kGuard>(nodes, off, C.px, C.py, C.pz, C.b64, P, C.band2, resume, tx, ty, tz, a_, f_, j_, b_);
+                dax += (double)tx; day += (double)ty; daz += (double)tz;
+            } else {
+                off = visit<kGuard>(nodes, off, C.px, C.py, C.pz, C.b64, P, C.band2, resume, ax, ay, az, a_, f_, j_, b_);
+            }
             if (kCount) {
                 wv += 1; lv += a_ ? 1 : 0; la += f_ ? 1 : 0; jm += j_ ? 1 : 0; bd += b_ ? 1 : 0;
 #pragma unroll
@@ -1105,6 +1154,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                 }
             }
         }
+        if (kCount && P.acc64) { acc64x = dax; acc64y = day; acc64z = daz; }
         if (kCount) {
             // wave_visits counted once per wave (lane 0), lane counters summed over lanes
             if (lane == 0) {
@@ -1120,10 +1170,11 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         }
     }
     if (kIntegrate) {
-        publish_maxabs(tab, valid ? integrate(tab, j, rank, ax, ay, az, P, frozen) : 0.0);
+        publish_maxabs(tab, valid ? integrate(tab, j, rank, sx + (double)ax, sy + (double)ay, sz + (double)az, P, frozen) : 0.0);
     } else if (valid) {
         const int64_t o = 3 * (int64_t)tab->buf[P.curbuf].id[j];
-        acc_out[o] = (double)ax; acc_out[o + 1] = (double)ay; acc_out[o + 2] = (double)az;
+        const bool d64 = kCount && P.acc64;
+        acc_out[o] = d64 ? acc64x : (double)ax; acc_out[o + 1] = d64 ? acc64y : (double)ay; acc_out[o + 2] = d64 ? acc64z : (double)az;
     }
 }
 
@@ -1144,7 +1195,7 @@ template <int K>
 __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ nodes, const WalkTable *tab,
                                                        const TreeInfo *info_in, const float4 *__restrict__ posm_s,
                                                        const uint32_t *__restrict__ perm, WalkParams P) {
-    __shared__ float part[K][3][64];
+    __shared__ double part[K][3][64];
     const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t rank = P.rank_begin + (int64_t)lb * 64 + lane;
@@ -1165,22 +1216,23 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     C.b64 = Body64{tab, P.curbuf, j};
     unsigned resume = valid ? 0u : 0xffffffffu;
     float ax = 0.f, ay = 0.f, az = 0.f;
+    double sx = 0.0, sy = 0.0, sz = 0.0;  // two-level sums, see NBMI_FLUSH
     // wave-uniform range (w is the wave index): tell the compiler so
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * w / K) * kNodeBytes);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * (w + 1) / K) * kNodeBytes);
     if (lo < hi) {
         const unsigned c0 = __builtin_amdgcn_readfirstlane(lo == 0u ? 0u : seek(C, P, lo, resume));
-        if (c0 < hi) walk_span<false>(C, P, c0, hi, resume, ax, ay, az);
+        if (c0 < hi) walk_span<false>(C, P, c0, hi, resume, ax, ay, az, sx, sy, sz);
     }
-    part[w][0][lane] = ax; part[w][1][lane] = ay; part[w][2][lane] = az;
+    part[w][0][lane] = sx + (double)ax; part[w][1][lane] = sy + (double)ay; part[w][2][lane] = sz + (double)az;
     __syncthreads();
     if (w != 0) return;
-    ax = part[0][0][lane]; ay = part[0][1][lane]; az = part[0][2][lane];
+    sx = part[0][0][lane]; sy = part[0][1][lane]; sz = part[0][2][lane];
 #pragma unroll
     for (int k = 1; k < K; k++) {
-        ax += part[k][0][lane]; ay += part[k][1][lane]; az += part[k][2][lane];
+        sx += part[k][0][lane]; sy += part[k][1][lane]; sz += part[k][2][lane];
     }
-    publish_maxabs(tab, valid ? integrate(tab, j, rank, ax, ay, az, P, frozen) : 0.0);
+    publish_maxabs(tab, valid ? integrate(tab, j, rank, sx, sy, sz, P, frozen) : 0.0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2231,6 +2283,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.xcd_chunk = s->xcd_chunk;
     P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
     P.curbuf = s->curbuf;
+    P.acc64 = getenv("NBMI_ACC64") ? atoi(getenv("NBMI_ACC64")) : 0;
 
     // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on
     // the size of the tree (not on the shard), so that every sharding adds up the same partial sums.
