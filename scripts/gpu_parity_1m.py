@@ -36,5 +36,18 @@ for s in range(1, steps + 1):
                "nodes_cpu": cpu.num_nodes, "elapsed_s": round(time.time() - t0, 1)}
         out.append(row)
         print(json.dumps(row), flush=True)
+# who holds the maximum?  the worst bodies, their error in length units and the distance to their nearest neighbour
+try:
+    from scipy.spatial import cKDTree
+    gp = gpu.get_positions_f64()
+    e = np.linalg.norm(gp - cpu.pos, axis=1)
+    worst = np.argsort(e)[-8:][::-1]
+    dist, idx = cKDTree(cpu.pos).query(cpu.pos[worst], k=2)
+    print(json.dumps({"worst_bodies": [{"body": int(b), "abs_err": float(e[b]), "nearest_neighbour_dist": float(d[1]),
+                                        "err_over_neighbour_dist": float(e[b] / d[1]), "neighbour": int(i[1]),
+                                        "neighbour_abs_err": float(e[i[1]])} for b, d, i in zip(worst, dist, idx)],
+                      "softening": 1.5, "largest_coordinate": float(np.abs(cpu.pos).max())}))
+except Exception as ex:  # diagnostics only
+    print(json.dumps({"worst_bodies_error": repr(ex)}))
 print(json.dumps({"summary": {"n": n, "steps": steps, "theta": 0.5, "dt": 0.05, "oracle": "strict float64, uncapped",
                               "max_rel_pos_err_final": out[-1]["max_rel_pos_err"], "threads": int(pyref.lib().nbref_num_threads())}}))
