@@ -387,7 +387,7 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f32 forces (f64 opening-test ties), f64 state/keys" if method == "barnes_hut"
+        "dtype": "f32 pair forces (f64 opening-test ties, sums emptied into f64 every 16 visits), f64 state/keys" if method == "barnes_hut"
                  else "f32 pair forces, f64 sums/state",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": workload, "distribution": dist_name.replace("_fast", ""),

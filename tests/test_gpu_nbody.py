@@ -33,7 +33,10 @@ def _sorted_cells(level, key):
 
 
 @pytest.mark.parametrize("name", TREES)
-def test_tree_bit_exact(gpu, oracle, name):
+@pytest.mark.parametrize("hilbert", [True, False], ids=["hilbert-order", "octant-order"])
+def test_tree_bit_exact(gpu, oracle, name, hilbert, monkeypatch):
+    if not hilbert:
+        monkeypatch.setenv("NBMI_HILBERT", "0")  # the plain octant digits as sort keys (measurement knob)
     g = golden(name)
     pos, mass = g["pos"], g["mass"]
     sim = _bh(gpu, pos, g["vel"], mass, float(g["G"]), float(g["eps"]))
@@ -48,7 +51,7 @@ def test_tree_bit_exact(gpu, oracle, name):
     # ... which the device keeps relabelled along the Hilbert curve: the raw sort keys equal the test-side mirror
     from hilbert_ref import hilbert_keys
     shi, slo = sim.sort_keys()
-    ehi, elo = hilbert_keys(ohi, olo)
+    ehi, elo = hilbert_keys(ohi, olo) if hilbert else (ohi, olo)
     assert np.array_equal(shi, ehi) and np.array_equal(slo, elo)
     assert np.array_equal(sim.key_order(), np.lexsort((np.arange(len(pos)), elo, ehi)).astype(np.int32))
     ll = g["leaf_level"].astype(np.uint64)
