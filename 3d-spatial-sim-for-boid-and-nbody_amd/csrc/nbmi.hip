@@ -784,38 +784,37 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     return any_open ? off + kNodeBytes : nd.next_off;
 }
 
-// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 17 VALU + 6 SALU + 2 SMEM
-// instructions per visit.  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.  The two deciding compares are
-// v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those that TAKE the node,
-// so the force instructions and the `resume` update need no per-lane selects; s_andn2 of the two
-// masks leaves "some lane opens" in SCC for the s_cselect that picks off + 24 / next_off; EXEC is
-// all-ones again before the next visit (every launched wave is full; lanes without a body carry
-// resume = ~0 and never take part).  The node record of the NEXT visit is requested as soon as its offset
-// is known - before the nine force instructions of the current visit are issued - into the other
-// of two SGPR banks (A = s[36:41], B = s[48:53]: cx cy cz gm s2t next_off), which
-// takes those instructions' issue time out of the per-wave dependent chain.  The whole loop is one
-// asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while
-// a load is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
-// Near-tie exit: one extra v_cmp against the lower band edge (s54 = s2t - band2); if a taking-part lane
-// lies inside the band the loop is left BEFORE this visit changes anything (cursor, resume, sums), the
-// caller performs that one visit in C++ with the float64 test and re-enters.
-#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI, EXITL) \
+// Hand-scheduled walk loop for the product kernel (eps > 0, no counters): 16 VALU + 3 SALU + 2 SMEM
+// instructions on a visit nobody opens (80 % of them).  s_load_dwordx4 + s_load_dwordx2 at an SGPR byte offset.
+// The two deciding compares are v_cmpx: EXEC narrows to the lanes that take part in the visit, then to those
+// that TAKE the node, so the force instructions and the `resume` update need no per-lane selects; s_andn2 of
+// the two masks leaves "some lane opens" in SCC.  Nobody opens: the cursor follows next_off.  Somebody opens
+// (20 % of the visits): a branch to an out-of-line block behind the loop (NBMI_OPEN_X), which holds everything
+// only such a visit needs - the near-tie check (only an opener can lie inside the uncertainty band: one v_cmp
+// of the openers against the lower band edge s2t - band2; a hit leaves the loop BEFORE the visit has changed
+// anything - cursor, resume, sums - the caller performs that one visit in C++ with the float64 test and
+// re-enters) and the step to the next node in memory - and comes back.  (Measured: walk 1.071 -> 1.053 ms at
+// 1 M, 10.23 -> 10.06 ms at 10 M against the check on every visit.)  EXEC is all-ones again before the next
+// visit (every launched wave is full; lanes without a body carry resume = ~0 and never take part).  The node
+// record of the NEXT visit is requested as soon as its offset is known - before the nine force instructions of
+// the current visit are issued - into the other of two SGPR banks (A = s[36:41], B = s[48:53]: cx cy cz gm s2t
+// next_off), which takes those instructions' issue time out of the per-wave dependent chain.  The whole loop
+// is one asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while a load
+// is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
+#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI, LOPEN, LJOIN) \
     "v_cmpx_ge_u32_e64 s[44:45], " OFF ", " RES "\n"           \
-    "s_add_u32 s58, " OFF ", 24\n"                             \
     WAIT                                                       \
-    "s_sub_u32 s54, " S2T ", %[band2]\n"                       \
     "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
     "v_sub_f32_e32 %[dy], " CY ", %[py]\n"                     \
     "v_sub_f32_e32 %[dz], " CZ ", %[pz]\n"                     \
     "v_fma_f32 %[d2], %[dx], %[dx], %[eps2]\n"                 \
     "v_fmac_f32_e32 %[d2], %[dy], %[dy]\n"                     \
     "v_fmac_f32_e32 %[d2], %[dz], %[dz]\n"                     \
-    "v_cmp_lt_i32_e64 s[42:43], s54, %[d2]\n"                  \
     "v_cmpx_lt_i32_e64 s[46:47], " S2T ", %[d2]\n"             \
-    "s_andn2_b64 s[42:43], s[42:43], s[46:47]\n"               \
-    "s_cbranch_scc1 " EXITL "\n"                               \
     "s_andn2_b64 s[56:57], s[44:45], s[46:47]\n"               \
-    "s_cselect_b32 " OFF ", s58, " NXT "\n"                    \
+    "s_cbranch_scc1 " LOPEN "f\n"                              \
+    "s_mov_b32 " OFF ", " NXT "\n"                             \
+    LJOIN ":\n"                                                \
     "s_load_dwordx4 " NEXTLO ", %[base], " OFF "\n"            \
     "s_load_dwordx2 " NEXTHI ", %[base], " OFF " offset:16\n"  \
     "v_rsq_f32_e32 %[inv], %[d2]\n"                            \
@@ -827,20 +826,37 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "v_fmac_f32_e32 %[ay" ACC "], %[dy], %[f]\n"               \
     "v_fmac_f32_e32 %[az" ACC "], %[dz], %[f]\n"               \
     "s_mov_b64 exec, -1\n"
+// the out-of-line half of a visit that some lane opens (s[56:57] = openers, s[46:47] = takers; 20 % of the visits):
+// only an opener can lie inside the uncertainty band, so the near-tie check lives here - one v_cmp of the openers
+// against the lower band edge; a hit leaves the loop BEFORE the visit has changed anything, otherwise the cursor
+// moves to the next node in memory and the visit goes on
+#define NBMI_OPEN_X(OFF, S2T, LOPEN, LJOIN, EXITL)   \
+    LOPEN ":\n"                                      \
+    "s_sub_u32 s54, " S2T ", %[band2]\n"             \
+    "s_mov_b64 exec, s[56:57]\n"                     \
+    "v_cmp_lt_i32_e64 s[42:43], s54, %[d2]\n"        \
+    "s_mov_b64 exec, s[46:47]\n"                     \
+    "s_cmp_lg_u64 s[42:43], 0\n"                     \
+    "s_cbranch_scc1 " EXITL "\n"                     \
+    "s_add_u32 " OFF ", " OFF ", 24\n"               \
+    "s_branch " LJOIN "b\n"
 #define NBMI_WAIT "s_waitcnt lgkmcnt(0)\n"
-#define NBMI_VISIT_A \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]", "7f")
-#define NBMI_VISIT_B \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]", "7f")
+#define NBMI_VISIT_A(LO, LJ) \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]", LO, LJ)
+#define NBMI_VISIT_B(LO, LJ) \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]", LO, LJ)
+#define NBMI_OPEN_A(LO, LJ) NBMI_OPEN_X("%[off]", "s40", LO, LJ, "7f")
+#define NBMI_OPEN_B(LO, LJ) NBMI_OPEN_X("%[off]", "s52", LO, LJ, "7f")
 // two cursors in one wave (walk_pair_asm): cursor 1 uses banks s[36:41] / s[48:53], cursor 2 uses
 // s[60:65] / s[68:73]; the trip waits ONCE for both cursors' records
 #define NBMI_VISIT_1A NBMI_VISIT_A
 #define NBMI_VISIT_1B NBMI_VISIT_B
-#define NBMI_VISIT_2A \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]", "8f")
-#define NBMI_VISIT_2B \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", "8f")
-// leaving the loop on a near-tie: all lanes back on, tell the caller which cursor stopped
+#define NBMI_VISIT_2A(LO, LJ) \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]", LO, LJ)
+#define NBMI_VISIT_2B(LO, LJ) \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", LO, LJ)
+#define NBMI_OPEN_2A(LO, LJ) NBMI_OPEN_X("%[off2]", "s64", LO, LJ, "8f")
+#define NBMI_OPEN_2B(LO, LJ) NBMI_OPEN_X("%[off2]", "s72", LO, LJ, "8f")
 // Two-level sums: the loops add into fp32 accumulators (one instruction per component and visit); every few
 // trips those are emptied into float64 sums (NBMI_FLUSH: convert, add, clear), so an fp32 running sum never grows
 // beyond a dozen terms.  Measured at 1 M bodies against the float64 oracle, per-body relative acceleration error:
@@ -862,8 +878,8 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "s_sub_u32 %[cnt], %[cnt], 1\n"     \
     "s_cbranch_scc1 40f\n"              \
     "41:\n"
-#define NBMI_EXITS(FLUSHES, TRIPS)      \
-    "s_branch 9f\n"                     \
+#define NBMI_EXITS(OPENS, FLUSHES, TRIPS) \
+    "s_branch 9f\n" OPENS               \
     "40:\n" FLUSHES                     \
     "s_mov_b32 %[cnt], " TRIPS "\n"     \
     "s_branch 41b\n"                    \
@@ -891,9 +907,11 @@ __device__ __forceinline__ void walk4_asm(const Node *nodes, unsigned &off, unsi
     asm volatile("s_mov_b32 %[cnt], 3\n"
                  "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A NBMI_VISIT_B NBMI_VISIT_A NBMI_VISIT_B NBMI_TRIP_COUNT
+                 "1:\n" NBMI_VISIT_A("21", "31") NBMI_VISIT_B("22", "32") NBMI_VISIT_A("23", "33") NBMI_VISIT_B("24", "34") NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n" NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "3")
+                 "s_cbranch_scc1 1b\n"
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_B("22", "32") NBMI_OPEN_A("23", "33") NBMI_OPEN_B("24", "34"),
+                            NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "3")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
                    [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
                    [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
@@ -913,11 +931,12 @@ __device__ __forceinline__ void walk1_asm(const Node *nodes, unsigned &off, unsi
     asm volatile("s_mov_b32 %[cnt], 7\n"
                  "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A
+                 "1:\n" NBMI_VISIT_A("21", "31")
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B NBMI_TRIP_COUNT
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B("22", "32") NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc1 1b\n" NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "7")
+                 "s_cbranch_scc1 1b\n"
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_B("22", "32"), NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "7")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
                    [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
                    [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
@@ -947,14 +966,15 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
                  "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
-                 "1:\n" NBMI_VISIT_1A NBMI_VISIT_2A
+                 "1:\n" NBMI_VISIT_1A("21", "31") NBMI_VISIT_2A("22", "32")
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n" NBMI_VISIT_1B NBMI_VISIT_2B
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_1B("23", "33") NBMI_VISIT_2B("24", "34")
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc0 9f\n" NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off2], %[end2]\n"
                  "s_cbranch_scc1 1b\n"
-                 NBMI_EXITS(NBMI_FLUSH("%[ax]", "%[ay]", "%[az]") NBMI_FLUSH("%[ax2]", "%[ay2]", "%[az2]"), "3")
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_2A("22", "32") NBMI_OPEN_B("23", "33") NBMI_OPEN_2B("24", "34"),
+                            NBMI_FLUSH("%[ax]", "%[ay]", "%[az]") NBMI_FLUSH("%[ax2]", "%[ay2]", "%[az2]"), "3")
                  : [off] "+s"(off1), [off2] "+s"(off2), [which] "+s"(which), [resume] "+v"(resume1),
                    [resume2] "+v"(resume2), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2),
                    [ay2] "+v"(ay2), [az2] "+v"(az2), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64),
