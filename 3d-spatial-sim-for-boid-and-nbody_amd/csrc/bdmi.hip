@@ -600,6 +600,7 @@ static int bd_create_impl(bdmi_flock *f, const double *pos, const double *vel, c
     char *t = nullptr;
     if (dev_alloc(f, &t, f->tmp_sort_bytes + 256)) return -2;
     f->tmp_sort = t;
+    NBMI_HIP_CHECK(nbmi::sort_init_temp(t, f->stream));
     if (n > 0) {
         double *dp = f->stage, *dv = dp + 3 * n, *dc = dv + 3 * n;
         NBMI_HIP_CHECK(hipMemcpyAsync(dp, pos, (size_t)n * 24, hipMemcpyHostToDevice, f->stream));
@@ -823,10 +824,23 @@ int bdmi_step(bdmi_flock *f, double dt, int substeps) {
     return 0;
 }
 
+// synchronise, then look at the radix sort's sticky error word (a timed-out look-back = a corrupt cell order)
+static int sync_checked(bdmi_flock *f) {
+    unsigned sort_err = 0u;
+    if (f->tmp_sort) NBMI_HIP_CHECK(nbmi::sort_error_word(f->tmp_sort, &sort_err, f->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+    if (sort_err) {
+        NBMI_HIP_CHECK(nbmi::sort_init_temp(f->tmp_sort, f->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
+        nbmi::set_error("device radix sort: a look-back spin timed out; the steps since the last synchronisation are invalid");
+        return -2;
+    }
+    return 0;
+}
+
 int bdmi_sync(bdmi_flock *f) {
     if (int rc = check(f)) return rc;
-    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
-    return 0;
+    return sync_checked(f);
 }
 
 int bdmi_get_state(bdmi_flock *f, double *pos, double *vel, double *col) {
@@ -848,8 +862,7 @@ int bdmi_get_state(bdmi_flock *f, double *pos, double *vel, double *col) {
         NBMI_HIP_CHECK(hipMemcpyAsync(col, dc, (size_t)n * 24, hipMemcpyDeviceToHost, f->stream));
     }
     NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(f->stream));
-    return 0;
+    return sync_checked(f);
 }
 
 int bdmi_set_state(bdmi_flock *f, const double *pos, const double *vel, const double *col) {

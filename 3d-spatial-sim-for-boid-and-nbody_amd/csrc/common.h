@@ -33,6 +33,8 @@ hipError_t sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit,
                               int end_bit, hipStream_t s);
 size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit);
+hipError_t sort_init_temp(void *temp, hipStream_t s);                          // once per freshly allocated temp buffer
+hipError_t sort_error_word(const void *temp, unsigned *out, hipStream_t s);  // sticky: 1 = some sort since then went wrong
 hipError_t sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                               const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit,
                               int end_bit, hipStream_t s);
@@ -44,6 +46,7 @@ hipError_t radix_sort_pairs_u64(void *temp, size_t temp_bytes, const uint64_t *k
                                 uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
 hipError_t radix_sort_pairs_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                                 uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s);
+hipError_t radix_init_temp(void *temp, hipStream_t s);
 hipError_t radix_error_word(const void *temp, unsigned *out, hipStream_t s);
 
 // One body of a key-sorted run as it travels between GPUs (multi-GPU run exchange): the two

@@ -222,6 +222,7 @@ int ic_generate(int distribution, int64_t n, double R, double G, uint64_t seed, 
     NBMI_HIP_CHECK(hipMalloc((void **)&S.ridx, n * 4));
     NBMI_HIP_CHECK(hipMalloc((void **)&S.ridx_s, n * 4));
     NBMI_HIP_CHECK(hipMalloc(&S.tmp, tmp_bytes + 256));
+    NBMI_HIP_CHECK(sort_init_temp(S.tmp, st));
     k_fill_mass_id<<<nblocks(n), kBlock, 0, st>>>(n, A.m, A.id);
     bool remove_com = false;
     if (distribution == NBMI_IC_GALAXY) {  // presets.py:104-146
@@ -250,7 +251,13 @@ int ic_generate(int distribution, int64_t n, double R, double G, uint64_t seed, 
         k_sub_mean3<<<nblocks(n), kBlock, 0, st>>>(A.vx, A.vy, A.vz, n, S.part, kSumBlocks);
     }
     NBMI_HIP_CHECK(hipGetLastError());
+    unsigned sort_err = 0u;
+    NBMI_HIP_CHECK(sort_error_word(S.tmp, &sort_err, st));
     NBMI_HIP_CHECK(hipStreamSynchronize(st));  // scratch is freed on return
+    if (sort_err) {
+        set_error("device radix sort: a look-back spin timed out while ranking the generated bodies");
+        return -2;
+    }
     return 0;
 }
 

@@ -531,7 +531,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
                                                         const float4 *__restrict__ posm_s, int64_t n, int64_t capacity,
                                                         Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
                                                         int32_t *__restrict__ node_ref, int32_t *__restrict__ cell_r,
-                                                        uint8_t *__restrict__ cell_lev, double eps, TreeInfo *info) {
+                                                        uint8_t *__restrict__ cell_lev, double eps, TreeInfo *info,
+                                                        const double4 *__restrict__ p64_s = nullptr,
+                                                        double4 *__restrict__ diag64 = nullptr) {
     const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (r < n) {
         const int64_t total = n + (int64_t)Pex[n];
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restric
             lf.s2t = 0.0f;
             lf.next_off = (unsigned)(idx + 1) * kNodeBytes;
             nodes[idx] = lf;
+            if (diag64) diag64[idx] = p64_s ? p64_s[r] : make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
             node_ref[idx] = (int32_t)r;
             node_level[idx] = (uint8_t)leaf_level;
             if (r == 0) {
@@ -607,7 +610,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
                                                        int64_t n, double eps, double inv_theta2, int64_t capacity,
                                                        Node *__restrict__ nodes, Node64 *__restrict__ nodes64,
                                                        uint8_t *__restrict__ node_level,
-                                                       int32_t *__restrict__ node_ref, const TreeInfo *__restrict__ info) {
+                                                       int32_t *__restrict__ node_ref, const TreeInfo *__restrict__ info,
+                                                       double4 *__restrict__ diag64 = nullptr) {
     const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t ncells = Pex[n];
     if (q >= ncells || n + ncells + 1 > capacity) return;
@@ -648,6 +652,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restric
     nd.next_off = (unsigned)(e + (int64_t)Pex[e]) * kNodeBytes;
     nodes[idx] = nd;
     nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
+    if (diag64) diag64[idx] = make_double4(cx, cy, cz, M);
     node_ref[idx] = (int32_t)r;
     node_level[idx] = (uint8_t)lev;
 }
@@ -714,6 +719,8 @@ struct WalkParams {
     double dt, damping;
     int curbuf;  // which of WalkTable.buf holds the current state
     int acc64;   // measurement (counted walk only, NBMI_ACC64=1): every visit's contribution summed in float64
+    int prec;    // measurement (k_walk_diag, NBMI_PREC=<mode>): which visits compute their force in which arithmetic
+    float near2; // k_walk_diag: "near" visits have fp32 dist_sq below this
 };
 
 // Per-handle constants the walk needs only rarely (float64 re-decision) or only at its end (the state
@@ -1368,6 +1375,97 @@ __global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ n
 }
 
 // ---------------------------------------------------------------------------------------
+// Measurement only (NBMI_PREC=<mode>): the lock-step walk in C++ with the product walk's opening decisions
+// (fp32 test, uncertainty band, float64 re-decision - the accepted sets are the product's) and a selectable
+// arithmetic for the force of an accepted visit.  Answers "which rounding makes the 100-step error at 1 M
+// bodies" (scripts/gpu_prec_diag.py).  diag64 = {cx, cy, cz, G m} of EVERY node in float64.
+//   1  fp32 pair arithmetic on fp32-rounded coordinates, every contribution added to float64 sums (= the product's
+//      arithmetic with ideal accumulation)
+//   2  float64 throughout
+//   3  float64 for leaves, 1 otherwise          4  float64 where fp32 dist_sq < near2, 1 otherwise
+//   5  two-word coordinates (hi + lo floats of body and node), fp32 arithmetic
+//   6  exact float64 differences rounded to fp32, then fp32 arithmetic (coordinate rounding removed altogether)
+//   7  as 1 with fp32 running sums (no float64 accumulation at all)
+//   8  as 6, one Newton step on the reciprocal square root
+//   9  as 2 but G m rounded to fp32
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ nodes, const double4 *__restrict__ diag64,
+                                                      const WalkTable *tab, const TreeInfo *info_in,
+                                                      const float4 *__restrict__ posm_s, const uint32_t *__restrict__ perm,
+                                                      WalkParams P) {
+    const int64_t rank = P.rank_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = rank < P.rank_end;
+    const bool frozen = info_in->error != 0 || info_in->sticky_error != 0;
+    const unsigned nn = frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeBytes);
+    const unsigned band2 = __builtin_amdgcn_readfirstlane(info_in->band2);
+    float px = 0.f, py = 0.f, pz = 0.f;
+    double qx = 0.0, qy = 0.0, qz = 0.0;
+    uint32_t j = 0;
+    if (valid) {
+        const float4 p = posm_s[rank];
+        px = p.x; py = p.y; pz = p.z;
+        j = perm[rank];
+        const Bodies &cur = tab->buf[P.curbuf];
+        qx = cur.x[j]; qy = cur.y[j]; qz = cur.z[j];
+    }
+    const float plx = (float)(qx - (double)px), ply = (float)(qy - (double)py), plz = (float)(qz - (double)pz);
+    const Body64 b64{tab, P.curbuf, j};
+    unsigned resume = valid ? 0u : 0xffffffffu;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    const int mode = P.prec;
+    const double eps2d = tab->eps2;
+    unsigned off = 0u;
+    while (off < nn) {
+        off = __builtin_amdgcn_readfirstlane(off);
+        const Node nd = *reinterpret_cast<const Node *>(reinterpret_cast<const char *>(nodes) + off);
+        const float dx = nd.cx - px, dy = nd.cy - py, dz = nd.cz - pz;
+        const float dist_sq = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, P.eps2)));
+        const bool active = resume <= off;
+        const int d2b = __float_as_int(dist_sq), hi = __float_as_int(nd.s2t), lo = hi - (int)band2;
+        bool geom = hi < d2b;
+        if (active && !geom && lo < d2b) geom = (hi == 0) || exact_take(off, b64);
+        const bool take = active && geom;
+        if (take) {
+            const bool leaf = hi == 0;
+            const bool use64 = mode == 2 || mode == 9 || (mode == 3 && leaf) || (mode == 4 && dist_sq < P.near2);
+            if (use64) {
+                const double4 c = diag64[off / kNodeBytes];
+                const double ex = c.x - qx, ey = c.y - qy, ez = c.z - qz;
+                const double d2 = ex * ex + ey * ey + ez * ez + eps2d;
+                const double inv = 1.0 / sqrt(d2);
+                const double gm = mode == 9 ? (double)nd.gm : c.w;
+                const double f = gm * inv * inv * inv;
+                sx += ex * f; sy += ey * f; sz += ez * f;
+            } else {
+                float ex = dx, ey = dy, ez = dz;
+                if (mode == 5) {
+                    const double4 c = diag64[off / kNodeBytes];
+                    const float clx = (float)(c.x - (double)nd.cx), cly = (float)(c.y - (double)nd.cy), clz = (float)(c.z - (double)nd.cz);
+                    ex = dx + (clx - plx); ey = dy + (cly - ply); ez = dz + (clz - plz);
+                } else if (mode == 6 || mode == 8) {
+                    const double4 c = diag64[off / kNodeBytes];
+                    ex = (float)(c.x - qx); ey = (float)(c.y - qy); ez = (float)(c.z - qz);
+                }
+                const float d2 = (mode == 5 || mode == 6 || mode == 8) ? fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, P.eps2))) : dist_sq;
+                float inv = __builtin_amdgcn_rsqf(d2);
+                if (mode == 8) inv = inv * fmaf(-0.5f * d2 * inv, inv, 1.5f);
+                const float f = (nd.gm * inv) * (inv * inv);
+                if (mode == 7) {
+                    fx = fmaf(ex, f, fx); fy = fmaf(ey, f, fy); fz = fmaf(ez, f, fz);
+                } else {
+                    sx += (double)(ex * f); sy += (double)(ey * f); sz += (double)(ez * f);
+                }
+            }
+            resume = nd.next_off;
+        }
+        const unsigned long long any_open = __builtin_amdgcn_ballot_w64(active && !geom);
+        off = any_open ? off + kNodeBytes : nd.next_off;
+    }
+    publish_maxabs(tab, valid ? integrate(tab, j, rank, sx + (double)fx, sy + (double)fy, sz + (double)fz, P, frozen) : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------
 // Direct O(N^2): a_i = sum_{j != i} G m_j d (|d|^2 + eps^2)^(-3/2)   (gpu_backend.py:145-240)
 // 256-thread blocks, IB bodies per thread, 256-body tiles of {x,y,z,G m} staged in LDS and read
 // back as wave-uniform broadcasts.  fp32 pair arithmetic, per-tile fp32 partial sums folded
@@ -1723,8 +1821,9 @@ constexpr int kMegasPerRank = 8, kSupersPerMega = kSupersPerRank / kMegasPerRank
 __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
                                                       const int32_t *__restrict__ node_ref, const uint64_t *__restrict__ hi_s,
                                                       const uint64_t *__restrict__ lo_s, const TreeInfo *__restrict__ info,
-                                                      int64_t n, int32_t *__restrict__ flag) {
+                                                      int64_t n, int64_t rows, int32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rows) return;  // the grid is rounded up to whole blocks: nothing behind the row budget is written
     const int64_t num_nodes = info->error ? 0 : info->num_nodes;
     if (i >= num_nodes) {
         flag[i] = 0;  // launched for the row budget: rows behind the tree count nothing
@@ -2064,6 +2163,7 @@ struct nbmi_sim {
     double G = 0, softening = 0, damping = 1, theta = 0.5;
     hipStream_t stream = nullptr;
     int curbuf = 0;
+    int64_t steps_taken = 0;  // nbmi_step_count()
     Bodies buf[2] = {};
     // scratch
     uint64_t *key_hi = nullptr, *key_lo = nullptr, *hi_s = nullptr, *lo_s = nullptr;
@@ -2125,6 +2225,9 @@ struct nbmi_sim {
     bool hilbert = true;  // sort keys relabelled along the Hilbert curve (k_keys); NBMI_HILBERT=0: plain octant digits
     int walk_stack = 0;  // prototype: stack walk with batched children (NBMI_WALK_STACK=1)
     int walk_lane = 0;  // measurement: per-lane walk (NBMI_WALK_LANE=1)
+    int prec = 0;       // measurement: k_walk_diag arithmetic mode (NBMI_PREC), 0 = product walk
+    double prec_near = 4.0;  // NBMI_PREC_NEAR: "near" = closer than this many softening lengths
+    double4 *diag64 = nullptr;  // float64 {cx, cy, cz, G m} of every node (only with NBMI_PREC)
     // one-wave walk: cursors per wave and where the array is cut.  -1 = by size: two cursors, cut at the middle of the
     // array, or (from kHomeSplitBodies = 1.5 M bodies on) at the leaf of the wave's middle body; NBMI_WALK_PAIR = 0 / 1 / 2 forces
     // one cursor / the middle cut / the home cut
@@ -2200,9 +2303,11 @@ int enqueue_maxabs(nbmi_sim *s) {
     }
     // reset maxabs/num_nodes/max_level/error (keep counters)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
+    if (n == 0) return 0;  // an owner-mode rank may hold no bodies: the cleared header is all there is (a 0-block launch is an error)
     int gb = nblocks(n);
     if (gb > 256) gb = 256;  // one same-address atomic per block: keep them few
     k_maxabs<<<gb, kBlock, 0, st>>>(cur.x, cur.y, cur.z, n, s->info);
+    NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
@@ -2258,11 +2363,12 @@ int enqueue_global_tree(nbmi_sim *s) {
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->own_node_rows, s->nodes,
-                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->softening, s->info);
+                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->softening, s->info,
+                                                 s->p64_s, s->diag64);
     // one thread per internal cell; the count lives on the device, so launch for the row budget
     k_emit_cells<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
                                                                   n, s->softening, inv_theta2, s->own_node_rows, s->nodes,
-                                                                  s->nodes64, s->node_level, s->node_ref, s->info);
+                                                                  s->nodes64, s->node_level, s->node_ref, s->info, s->diag64);
     if (s->walk_stack)
         k_child_table<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->nodes, s->Pex, s->cell_r, n, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
@@ -2304,6 +2410,13 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
     P.curbuf = s->curbuf;
     P.acc64 = getenv("NBMI_ACC64") ? atoi(getenv("NBMI_ACC64")) : 0;
+    P.prec = s->prec;
+    P.near2 = (float)(s->prec_near * s->prec_near * s->softening * s->softening);
+    if (integrate && s->prec && s->diag64 && !guard && !s->owner) {  // measurement only, see k_walk_diag
+        k_walk_diag<<<(int)((cntr + kBlock - 1) / kBlock), kBlock, 0, st>>>(s->nodes, s->diag64, s->wtab, s->info, s->posm_s, s->perm, P);
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 
     // few groups: a block of K waves per group, each walking one K-th of the array.  K depends only on
     // the size of the tree (not on the shard), so that every sharding adds up the same partial sums.
@@ -2383,8 +2496,17 @@ int launch_direct(nbmi_sim *s, double dt, double *acc_out) {
 
 int check_device_error(nbmi_sim *s) {
     TreeInfo h;
+    unsigned sort_err = 0u;
     NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, s->stream));
+    if (s->tmp_sort) NBMI_HIP_CHECK(nbmi::sort_error_word(s->tmp_sort, &sort_err, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (sort_err) {  // a look-back spin of the radix sort timed out: that pass scattered to wrong offsets
+        NBMI_HIP_CHECK(nbmi::sort_init_temp(s->tmp_sort, s->stream));
+        NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->tree_valid = false;
+        nbmi::set_error("device radix sort: a look-back spin timed out; the steps since the last synchronisation are invalid");
+        return NBMI_ERR_HIP;
+    }
     if (h.max_run > 4096 && s->sort_bits < 63) {
         // many bodies agree on the sorted prefix (a dense core inside one level-13 cell): the tie-fix did the
         // rest correctly but at L reads per member - sort on more bits from the next step on
@@ -2443,6 +2565,8 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_HILBERT")) s->hilbert = atoi(e) != 0;
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
     if (const char *e = getenv("NBMI_WALK_STACK")) s->walk_stack = atoi(e);
+    if (const char *e = getenv("NBMI_PREC")) s->prec = atoi(e);
+    if (const char *e = getenv("NBMI_PREC_NEAR")) s->prec_near = atof(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {
         const int b = atoi(e);
         if (b >= 8 && b <= 63) s->sort_bits = b;
@@ -2478,6 +2602,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
             (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
+            (s->prec && dev_alloc(s, &s->diag64, own_rows)) ||
             dev_alloc(s, &s->cell_r, own_rows - c) || dev_alloc(s, &s->cell_lev, own_rows - c))
             return -2;
         s->own_node_rows = own_rows;
@@ -2485,6 +2610,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         char *t = nullptr;
         if (dev_alloc(s, &t, s->tmp_sort_bytes + 256)) return -2;
         s->tmp_sort = t;
+        NBMI_HIP_CHECK(nbmi::sort_init_temp(t, s->stream));
         if (dev_alloc(s, &s->wtab, 1) || upload_walk_table(s)) return -2;
     }
     // upload AoS host arrays through the staging buffer and split to SoA
@@ -2629,6 +2755,7 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
             // a full (unsharded) step leaves every rank of the other buffer written
             // (sharded handles: the ranks outside [shard_begin, shard_end) arrive via nbmi_import_ranks)
             s->curbuf ^= 1;
+            s->steps_taken++;
             s->tree_valid = false;
             s->maxabs_fused = s->fuse_maxabs && s->shard_begin == 0 && s->shard_end == s->n && !s->walk_stack && !s->walk_lane;
         } else {
@@ -2643,10 +2770,13 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
                 s->timed_steps++;
             }
             s->curbuf ^= 1;
+            s->steps_taken++;
         }
     }
     return 0;
 }
+
+int64_t nbmi_step_count(nbmi_sim *s) { return s ? s->steps_taken : -1; }
 
 int nbmi_compute_colors(nbmi_sim *s, double max_speed) {
     if (int rc = check_handle(s)) return rc;
@@ -3105,7 +3235,7 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
         // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags).  The node count lives on
         // the device: launch for the row budget, the kernels stop at num_nodes themselves.
         const int64_t rows = s->own_node_rows;
-        k_box_flags<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, s->info, n_new, s->let_keep);
+        k_box_flags<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, s->info, n_new, rows, s->let_keep);
         if (int rc = enqueue_iscan(s, s->let_keep, rows, s->let_scan)) return rc;
         NBMI_HIP_CHECK(hipMemsetAsync(s->let_ranges, 0, sizeof(int32_t) * 2 * kBoxesPerRank, st));
         k_box_ranges<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, s->info, rows, n_new, s->let_ranges);

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include <stddef.h>
 
 namespace nbmi {
 namespace {
@@ -35,9 +36,11 @@ constexpr int kLookBatch = 8;
 constexpr int kMaxPasses = 8;
 
 struct Control {                 // lives at the start of the temp buffer
+    unsigned error;              // 1: a look-back spin timed out.  STICKY: cleared by radix_init_temp() only, not by the
+    unsigned pad0[15];           // per-sort clear (which starts at tile_ticket), so that the owner of the buffer still
+                                 // finds it at its next synchronisation however many sorts have run since
     unsigned tile_ticket[kMaxPasses];
-    unsigned error;              // 1: a look-back spin timed out
-    unsigned pad[7];
+    unsigned pad[8];
     unsigned hist[kMaxPasses][kBins];  // global digit counts, then exclusive offsets
 };
 
@@ -266,7 +269,9 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
     const size_t status_bytes = align256((size_t)passes * tiles * kBins * sizeof(unsigned));
     K *ktmp = (K *)((char *)status + status_bytes);
     uint32_t *vtmp = (uint32_t *)((char *)ktmp + align256(n * sizeof(K)));
-    hipError_t e = hipMemsetAsync(base, 0, align256(sizeof(Control)) + status_bytes, st);
+    // everything but the sticky error word at the head of the control block
+    hipError_t e = hipMemsetAsync(base + offsetof(Control, tile_ticket), 0,
+                                  align256(sizeof(Control)) - offsetof(Control, tile_ticket) + status_bytes, st);
     if (e != hipSuccess) return e;
     int hb = (int)((n + kThreads * 8 - 1) / (kThreads * 8));
     if (hb > 1024) hb = 1024;
@@ -300,8 +305,11 @@ hipError_t radix_sort_pairs_u32(void *temp, size_t temp_size, const uint32_t *ki
                                 uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t s) {
     return sort_pairs<uint32_t>(temp, temp_size, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
-// 1 if a look-back of the last sort on this temp buffer timed out (never observed; the spin is bounded so
-// that a lost status word cannot hang the GPU)
+// A freshly allocated temp buffer: clears the sticky error word (once, by whoever allocated the buffer).
+hipError_t radix_init_temp(void *temp, hipStream_t s) { return hipMemsetAsync(temp, 0, offsetof(Control, tile_ticket), s); }
+// 1 if a look-back of ANY sort on this temp buffer since radix_init_temp() timed out (never observed; the spin is
+// bounded so that a lost status word cannot hang the GPU).  Such a pass scattered to wrong offsets: the product
+// paths read this word wherever they synchronise anyway and report NBMI_ERR_HIP.
 hipError_t radix_error_word(const void *temp, unsigned *out, hipStream_t s) {
     return hipMemcpyAsync(out, &((const Control *)temp)->error, sizeof(unsigned), hipMemcpyDeviceToHost, s);
 }

@@ -48,6 +48,17 @@ hipError_t sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin
     return radix_sort_pairs_u64(temp, temp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit, s);
 }
 
+// The sticky error word of the hand-written sort (radix.hip) behind the dispatcher: rocPRIM owns the whole temp
+// buffer when it is selected and has no such word.
+hipError_t sort_init_temp(void *temp, hipStream_t s) { return radix_init_temp(temp, s); }
+hipError_t sort_error_word(const void *temp, unsigned *out, hipStream_t s) {
+    if (use_rocprim()) {
+        *out = 0u;
+        return hipSuccess;
+    }
+    return radix_error_word(temp, out, s);
+}
+
 size_t sort_pairs32_temp_bytes(size_t n, int begin_bit, int end_bit) {
     const size_t a = rocprim_bytes_u32(n, begin_bit, end_bit), b = radix_temp_bytes_u32(n, end_bit - begin_bit);
     return a > b ? a : b;
@@ -85,7 +96,7 @@ extern "C" int nbmi_debug_sort_pairs(int key_bytes, int64_t n, const void *keys,
     };
     hipError_t e;
     if ((e = hipMalloc(&dk, kb)) || (e = hipMalloc(&dko, kb)) || (e = hipMalloc(&dv, vb)) || (e = hipMalloc(&dvo, vb)) ||
-        (e = hipMalloc(&tmp, tb)) || (e = hipStreamCreate(&st)) || (e = hipEventCreate(&e0)) || (e = hipEventCreate(&e1)) ||
+        (e = hipMalloc(&tmp, tb)) || (e = hipStreamCreate(&st)) || (e = nbmi::radix_init_temp(tmp, st)) || (e = hipEventCreate(&e0)) || (e = hipEventCreate(&e1)) ||
         (e = hipMemcpyAsync(dk, keys, kb, hipMemcpyHostToDevice, st)) ||
         (e = hipMemcpyAsync(dv, values, vb, hipMemcpyHostToDevice, st)))
         fail("setup", e);

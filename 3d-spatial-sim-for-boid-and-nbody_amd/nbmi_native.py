@@ -26,6 +26,7 @@ PROTOTYPES = {
     "nbmi_get_masses_f64": (C.c_int, [_vp, _vp]),
     "nbmi_destroy": (None, [_vp]),
     "nbmi_step": (C.c_int, [_vp, _dbl, C.c_int]),
+    "nbmi_step_count": (_i64, [_vp]),
     "nbmi_compute_colors": (C.c_int, [_vp, _dbl]),
     "nbmi_get_positions_f32": (C.c_int, [_vp, _vp]),
     "nbmi_get_velocities_f64": (C.c_int, [_vp, _vp]),

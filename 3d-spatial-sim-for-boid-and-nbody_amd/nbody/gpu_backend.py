@@ -161,6 +161,10 @@ class _HIPSimulation:
         """`substeps` steps enqueued back to back without host round trips."""
         _nat.check(self._lib.nbmi_step(self._h, float(dt), int(substeps)), "nbmi_step")
 
+    def step_count(self) -> int:
+        """Steps the device has been asked to take since the handle was created (counted by the library)."""
+        return int(self._lib.nbmi_step_count(self._h))
+
     def get_positions_f64(self) -> np.ndarray:
         out = np.empty((self.n, 3), dtype=np.float64)
         _nat.check(self._lib.nbmi_get_positions_f64(self._h, _nat.ptr(out)), "nbmi_get_positions_f64")

@@ -331,29 +331,36 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
             rec_dir / f"state_{frame:04d}.npz", positions=gpu_sim.get_positions_f64(),
             velocities=gpu_sim.get_velocities(), masses=masses)
 
-    frame, stepped = start_frame - 1, False
+    def write_keyframe(frame):  # a frame that does not depend on the delta chain (format 1 is legal anywhere)
+        gpu_sim.compute_colors(15.0)
+        zf, _ = _frame_paths(rec_dir, frame)
+        p32, c32 = gpu_sim.frame_keyframe()
+        zf.write_bytes(pack_container(1, p32.tobytes(), c32.tobytes()))
+
+    frame = start_frame - 1
     try:
         for frame in range(start_frame, total_frames):
-            stepped = False
             gpu_sim.step_many(dt, substeps)
-            stepped = True
             write_frame(frame)
-            stepped = False
             if (frame + 1) % STATE_EVERY == 0:
                 write_state(frame)
                 old = rec_dir / f"state_{frame - STATE_EVERY:04d}.npz"
                 if old.exists():
                     old.unlink()
     except KeyboardInterrupt:
-        # reference :916-935: "Paused at frame N" + a state file so that --resume continues from there.  The
-        # device may be one frame ahead of the disk: finish that frame first, then checkpoint it.
-        if stepped:
-            write_frame(frame)
-        last = frame if (stepped or frame >= start_frame and _frame_paths(rec_dir, frame)[0].exists()
-                         or _frame_paths(rec_dir, frame)[1].exists()) else frame - 1
-        if last >= 0:
-            write_state(last, compressed=True)
-        say(f"\n[Record] Paused at frame {last}; resume with record(config, resume=True)")
+        # reference :916-935: "Paused at frame N" + a state file so that --resume continues from there.  Which
+        # frame the DEVICE stands at is asked of the library (the interrupt is delivered when the step call
+        # returns, before this loop could note anything): the checkpoint must be the state of exactly the last
+        # frame on disk, or a resume would skip or repeat one frame interval.
+        at = start_frame - 1 + gpu_sim.step_count() // max(substeps, 1)
+        if at >= 0:
+            on_disk = any(q.exists() for q in _frame_paths(rec_dir, at))
+            if at == frame and not on_disk:
+                # stepped, frame not written (or its write was cut short: the device-side delta chain may already
+                # have moved on, so this frame is written absolute)
+                write_keyframe(at) if direct_zstd else write_frame(at)
+            write_state(at, compressed=True)
+        say(f"\n[Record] Paused at frame {at}; resume with record(config, resume=True)")
         gpu_sim.close()
         raise
     say(f"[Record] {total_frames - start_frame} frames in {time.time() - t0:.2f}s -> {rec_dir}")

@@ -73,6 +73,11 @@ void nbmi_destroy(nbmi_sim *sim);
  * frame, tools/record.py:823-824).  Barnes-Hut: bounds -> keys -> sort -> octree -> walk with the
  * reference's kick-drift update fused in (simulation.py:308-317, 63-198, 201-278, 281-305). */
 int nbmi_step(nbmi_sim *sim, double dt, int substeps);
+/* Number of steps enqueued on this handle since it was created (every substep of nbmi_step counts).  The
+ * recorder's Ctrl-C path asks the library, not its own bookkeeping, which frame the device has reached: an
+ * interrupt is delivered when nbmi_step returns, before the caller can note that the step was taken
+ * (tools/record.py:916-935 writes "state at the frame the device is at"). */
+int64_t nbmi_step_count(nbmi_sim *sim);
 
 /* compute_colors(max_speed): gpu_backend.py:388-392 (ramp of simulation.py:320-400). */
 int nbmi_compute_colors(nbmi_sim *sim, double max_speed);

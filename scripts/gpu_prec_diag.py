@@ -1,0 +1,51 @@
+"""Which rounding makes the 100-step position error at BASELINE config 2 (galaxy, 1 M bodies, theta 0.5, dt 0.05)?
+Runs the GPU for 100 steps once per arithmetic mode of k_walk_diag (NBMI_PREC, see csrc/nbmi.hip; 0 = the product
+walk) and compares with the oracle trajectory cached by scripts/oracle_traj_cache.py (tests/cache/, made in the build
+container: the oracle costs ~4 minutes of the GPU box's CPU otherwise).  One JSON line per (mode, snapshot)."""
+import glob
+import importlib
+import json
+import os
+import re
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+importlib.import_module("3d-spatial-sim-for-boid-and-nbody_amd")
+import numpy as np  # noqa: E402
+from nbody.gpu_backend import HIPBarnesHutSimulation  # noqa: E402
+from tools.presets import generate_distribution  # noqa: E402
+
+n = int(os.environ.get("N", 1_000_000))
+modes = os.environ.get("MODES", "0,1,2,3,4,5,6,7").split(",")
+snaps = {}
+for f in glob.glob(os.path.join(ROOT, "tests", "cache", f"oracle_galaxy_{n}_step*.npy")):
+    snaps[int(re.search(r"step(\d+)", f).group(1))] = f
+steps = max(snaps)
+np.random.seed(42)
+p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
+for mode in modes:
+    # "4:8" = mode 4 with NBMI_PREC_NEAR=8
+    md, _, near = mode.partition(":")
+    os.environ.pop("NBMI_PREC", None)
+    os.environ.pop("NBMI_PREC_NEAR", None)
+    if md != "0":
+        os.environ["NBMI_PREC"] = md
+    if near:
+        os.environ["NBMI_PREC_NEAR"] = near
+    gpu = HIPBarnesHutSimulation(p, v, m, 0.07, 1.5, 1.0, 0.5)
+    t0 = time.time()
+    for s in range(1, steps + 1):
+        gpu.step(0.05)
+        if s in snaps:
+            ref = np.load(snaps[s])
+            gp = gpu.get_positions_f64()
+            err = np.abs(gp - ref)
+            scale = np.abs(ref).max()
+            row = {"mode": mode, "step": s, "max": float(err.max() / scale), "rms": float(np.sqrt((err ** 2).mean()) / scale),
+                   "p999": float(np.quantile(err.max(axis=1), 0.999) / scale),
+                   "p9999": float(np.quantile(err.max(axis=1), 0.9999) / scale),
+                   "n_over_1e-5": int((err.max(axis=1) / scale > 1e-5).sum()), "gpu_s": round(time.time() - t0, 2)}
+            print(json.dumps(row), flush=True)
+    del gpu

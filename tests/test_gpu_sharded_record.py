@@ -376,3 +376,45 @@ def test_record_direct_zstd_extend_and_interrupt(gpu, tmp_path, monkeypatch):
     a, _ = rec.load_frame(ti, 11)
     b, _ = rec.load_frame(raw, 11)
     assert np.abs(a - b).max() < 0.06  # raw frames vs the (lossy) compressed copy of the uninterrupted run
+
+
+@pytest.mark.parametrize("zstd", [False, True])
+def test_interrupt_delivered_when_the_step_call_returns(gpu, tmp_path, monkeypatch, zstd):
+    """Ctrl-C is delivered when nbmi_step returns - the device has advanced, the loop has noted nothing.
+    The checkpoint must be the state of the last frame on disk: the resumed recording equals the uninterrupted one."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from tools import record as rec
+    from tools.presets import get_preset_config
+    if zstd:
+        try:
+            rec._load_zstd()
+        except RuntimeError:
+            pytest.skip("no libzstd")
+    cfg = get_preset_config("quick_galaxy")
+    cfg.update(num_bodies=2000, theta=0.5, total_frames=9, substeps=3, zstd=zstd)
+    whole = rec.record(dict(cfg, session_name="t_whole"), root=tmp_path, quiet=True, seed=11)
+    real = HIPBarnesHutSimulation.step_many
+    calls = {"n": 0}
+
+    def stepping(self, dt, substeps):
+        real(self, dt, substeps)
+        calls["n"] += 1
+        if calls["n"] == 5:  # frame 4 has been stepped on the device, nothing of it is on disk
+            raise KeyboardInterrupt
+
+    monkeypatch.setattr(HIPBarnesHutSimulation, "step_many", stepping)
+    with pytest.raises(KeyboardInterrupt):
+        rec.record(dict(cfg, session_name="t_cut"), root=tmp_path, quiet=True, seed=11)
+    monkeypatch.setattr(HIPBarnesHutSimulation, "step_many", real)
+    cut = tmp_path / "recordings" / "t_cut"
+    assert rec.get_completed_frames(cut) == 5 and (cut / "state_0004.npz").exists()
+    with np.load(cut / "state_0004.npz") as st:
+        p4, _ = rec.load_frame(whole, 4)
+        tol = 2e-3 if zstd else 1e-6  # the lossy codec's quantum is 1e-3
+        assert np.abs(st["positions"].astype(np.float32) - p4).max() <= tol * max(1.0, float(np.abs(p4).max()))
+    rec.record(dict(cfg, session_name="t_cut"), resume=True, root=tmp_path, quiet=True)
+    assert rec.get_completed_frames(cut) == 9
+    for k in range(9):
+        a, _ = rec.load_frame(cut, k)
+        b, _ = rec.load_frame(whole, k)
+        assert np.abs(a - b).max() <= (4e-3 if zstd else 1e-5), k
