@@ -75,6 +75,17 @@ constexpr unsigned kNodeBytes = 24;
 struct alignas(16) Node64 {
     double cx, cy, cz, hs;
 };
+// [r3] The float64 node record, one per node (leaves too), read by the waves that compute their forces in float64
+// (k_walk, "force precision"): centre of mass / body position and G m as the float64 state has them, the opening
+// threshold and the skip link.  Same pre-order as `Node`; links are byte offsets in units of THIS record.
+struct alignas(8) NodeD {
+    double cx, cy, cz, gm;
+    float s2t;          // as Node::s2t
+    unsigned next_off;  // index * 40
+};
+constexpr unsigned kNodeDBytes = 40;
+static_assert(sizeof(NodeD) == kNodeDBytes, "NodeD must be 40 bytes");
+constexpr int64_t kMaxNodeDRows = 107000000;  // 32-bit byte offsets: 2^32 / 40
 // Node links are 32-bit byte offsets: at most 2^32 / 24 rows.  The reference allocates min(8 M, 4N)
 // rows (simulation.py:477) and uses ~1.5 N; this build allocates 4N + 4096 rows up to that ceiling,
 // which still leaves 1.7 N rows at the largest supported body count.
@@ -329,52 +340,30 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------
-// K5 + K6: gather bodies into key order - fp32 {x,y,z,G*m} (walk / leaf data), the same in float64 (input of
-// the moment prefix sums), the low key word - and, from the sorted keys of the two neighbours,
-//   delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1);
-//   cnt[r]   = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]).
-// (A neighbour's low key word is only fetched when the upper words agree: 21 common digits, rare.)
+// K5 - K7 [r3]: ONE pass puts the bodies in key order and lays the ground for every cell's mass and centre of mass.
+// A workgroup owns a tile of kScanTile = 2048 sorted ranks, swept in 8 rounds of 256 consecutive ranks (a SUB-TILE):
+//   * gather through the sort permutation: fp32 {x,y,z,G m} (walk / leaf data), the low key word;
+//   * from the sorted keys of the two neighbours
+//       delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1),
+//       cnt[r]   = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]);
+//   * exclusive prefix sums INSIDE the sub-tile (plain float64, straight from the float64 state):
+//       S[r]    = sum over the sub-tile's bodies before r of {G m, G m x, G m y, G m z}     (32 bytes)
+//       PexL[r] = the same for cnt
+//     and the sub-tile's totals (sub_tot / sub_cnt).
+// k_scan_subtiles then turns the totals into exclusive prefixes over the sub-tiles (T: double-double, subPex).
+// A cell's moments are   (T[sub(e)] - T[sub(r)])  +  (S[e] - S[r])   for its body range [r, e):
+// the first difference is exact to 1e-32 (double-double), the second is between sums of at most 255 terms, so a
+// cell's centre of mass is good to ~1e-14 of the coordinate wherever the cell sits in the array.  (A plain float64
+// running sum over 10^6 bodies loses 1e-8, the size of the opening-test ties K9 re-decides in float64; round 2
+// carried double-double sums through a three-phase scan of 64-byte records instead - 1.0 GB more traffic at 10 M
+// bodies and three more kernels.)  Pre-order index helpers: pex_at(r) = subPex[r / 256] + PexL[r].
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_gather(Bodies cur, const uint32_t *__restrict__ perm,
-                                                   const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
-                                                   int64_t n, double G, float4 *__restrict__ posm_s,
-                                                   double4 *__restrict__ p64_s, uint64_t *__restrict__ lo_s,
-                                                   int32_t *__restrict__ delta, int32_t *__restrict__ cnt) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r == 0) cnt[n] = 0;
-    if (r >= n) return;
-    const uint32_t j = perm[r];
-    const double x = cur.x[j], y = cur.y[j], z = cur.z[j], gm = G * cur.m[j];
-    posm_s[r] = make_float4((float)x, (float)y, (float)z, (float)gm);
-    p64_s[r] = make_double4(x, y, z, gm);  // float64 twin: input of the moment sums (coalesced there)
-    const uint64_t h = hi_s[r], l = key_lo[j];
-    lo_s[r] = l;
-    int d = -1, dp = -1;
-    if (r + 1 < n) {
-        const uint64_t hn = hi_s[r + 1];
-        d = cpl_digits(h, l, hn, hn == h ? key_lo[perm[r + 1]] : 0ull);
-    }
-    if (r > 0) {
-        const uint64_t hp = hi_s[r - 1];
-        dp = cpl_digits(hp, hp == h ? key_lo[perm[r - 1]] : 0ull, h, l);
-    }
-    delta[r] = d;
-    cnt[r] = d > dp ? d - dp : 0;
-}
+constexpr int kScanItems = 8;                      // rounds (sub-tiles) per workgroup
+constexpr int kScanTile = kBlock * kScanItems;     // 2048 ranks per workgroup
+constexpr int kSubShift = 8;                       // sub-tile = 256 ranks = one round
+static_assert(kBlock == (1 << kSubShift), "a sub-tile is one round of the workgroup");
 
-// ---------------------------------------------------------------------------------------
-// K7: exclusive prefix sums over the sorted bodies, three hand-written phases (reduce per tile ->
-// scan of the tile sums -> scan inside the tiles).  One pass produces both
-//   S[r]   = sum_{i<r} {G m, G m x, G m y, G m z}   (double-double, formed on the fly from the float64 state), and
-//   Pex[r] = sum_{i<r} cnt[i]
-// with S[n], Pex[n] = totals.  (rocPRIM's look-back scan of the 32-byte struct ran at ~1 TB/s.)
-// ---------------------------------------------------------------------------------------
-constexpr int kScanItems = 8;                      // elements per thread
-constexpr int kScanTile = kBlock * kScanItems;     // 2048 elements per block
-
-// double-double (unevaluated sum of two float64): the moment sums must give a cell's centre of mass to
-// float64 accuracy however far along the array the cell sits - a plain float64 running sum of 10^6
-// terms loses ~1e-8, which is the size of the opening-test ties the float64 re-decision (K9) exists for.
+// double-double (unevaluated sum of two float64)
 struct dd {
     double h, l;
 };
@@ -386,127 +375,149 @@ __device__ __forceinline__ dd dd_add(const dd &a, const dd &b) {
     const double h = s + e;
     return dd{h, e - (h - s)};
 }
-__device__ __forceinline__ dd dd_mul(double a, double b) {
-    const double p = a * b;
-    return dd{p, fma(a, b, -p)};
-}
 __device__ __forceinline__ double dd_diff(const dd &a, const dd &b) {  // a - b, rounded once
     const dd d = dd_add(a, dd{-b.h, -b.l});
     return d.h + d.l;
 }
 
-struct ScanVal {
-    dd m, x, y, z;
+__device__ __forceinline__ int64_t pex_at(const int32_t *__restrict__ PexL, const int32_t *__restrict__ subPex, int64_t r) {
+    return (int64_t)subPex[r >> kSubShift] + PexL[r];
+}
+
+struct Mom4 {
+    double m, x, y, z;
     int c;
 };
-__device__ __forceinline__ ScanVal sv_zero() { return ScanVal{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, 0}; }
-__device__ __forceinline__ ScanVal sv_add(const ScanVal &a, const ScanVal &b) {
-    return ScanVal{dd_add(a.m, b.m), dd_add(a.x, b.x), dd_add(a.y, b.y), dd_add(a.z, b.z), a.c + b.c};
-}
-// Where the sorted bodies' moments come from: the float64 records k_gather wrote in key order (single GPU
-// and row-exchange shards), or fp32 records received from other ranks (run exchange).
-struct MomentSrc {
-    const double4 *p64;   // {x, y, z, G m} in key order, or nullptr
-    const float4 *posm;   // fallback: fp32 {x,y,z,G m}
-};
-__device__ __forceinline__ ScanVal sv_load(const MomentSrc &src, const int32_t *__restrict__ cnt, int64_t i, int64_t n) {
-    if (i >= n) return sv_zero();
-    double gm, x, y, z;
-    if (src.p64) {
-        const double4 q = src.p64[i];
-        x = q.x; y = q.y; z = q.z; gm = q.w;
-    } else {
-        const float4 p = src.posm[i];
-        gm = (double)p.w; x = (double)p.x; y = (double)p.y; z = (double)p.z;
-    }
-    return ScanVal{{gm, 0.0}, dd_mul(gm, x), dd_mul(gm, y), dd_mul(gm, z), cnt[i]};
-}
-__device__ __forceinline__ dd dd_shfl_up(const dd &v, int d) { return dd{__shfl_up(v.h, d), __shfl_up(v.l, d)}; }
-__device__ __forceinline__ ScanVal sv_shfl_up(const ScanVal &v, int d) {
-    return ScanVal{dd_shfl_up(v.m, d), dd_shfl_up(v.x, d), dd_shfl_up(v.y, d), dd_shfl_up(v.z, d), __shfl_up(v.c, d)};
-}
-// inclusive scan across the 256 threads of a block; returns the thread's inclusive value and the
-// block total in `total`
-__device__ __forceinline__ ScanVal block_inclusive_scan(ScanVal v, ScanVal *lds /* kBlock/64 */, ScanVal &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const ScanVal o = sv_shfl_up(v, d);
-        if (lane >= d) v = sv_add(o, v);
-    }
-    if (lane == 63) lds[wave] = v;
-    __syncthreads();
-    ScanVal off = sv_zero();
-    total = sv_zero();
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) {
-        if (w < wave) off = sv_add(off, lds[w]);
-        total = sv_add(total, lds[w]);
-    }
-    __syncthreads();
-    return sv_add(off, v);
+__device__ __forceinline__ Mom4 m4_add(const Mom4 &a, const Mom4 &b) { return Mom4{a.m + b.m, a.x + b.x, a.y + b.y, a.z + b.z, a.c + b.c}; }
+__device__ __forceinline__ Mom4 m4_shfl_up(const Mom4 &v, int d) {
+    return Mom4{__shfl_up(v.m, d), __shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.c, d)};
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_reduce(MomentSrc src, const int32_t *__restrict__ cnt,
-                                                        int64_t n, ScanVal *__restrict__ tile_sum) {
-    __shared__ ScanVal lds[kBlock / 64];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile;
-    ScanVal acc = sv_zero();
-#pragma unroll
-    for (int k = 0; k < kScanItems; k++)  // strided: coalesced loads
-        acc = sv_add(acc, sv_load(src, cnt, base + (int64_t)k * kBlock + threadIdx.x, n));
-    ScanVal total;
-    (void)block_inclusive_scan(acc, lds, total);
-    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
-}
-
-// exclusive value of each thread from the block-inclusive ones (no floating-point subtraction)
-__device__ __forceinline__ ScanVal block_exclusive_from_inclusive(const ScanVal &inc, ScanVal *excl /* kBlock */) {
-    excl[threadIdx.x] = inc;
-    __syncthreads();
-    const ScanVal r = threadIdx.x > 0 ? excl[threadIdx.x - 1] : sv_zero();
-    __syncthreads();
-    return r;
-}
-
-// one block: exclusive scan of the tile sums in place (sequential over chunks of kBlock tiles)
-__global__ __launch_bounds__(kBlock) void k_scan_tiles(ScanVal *__restrict__ tile_sum, int64_t ntiles) {
-    __shared__ ScanVal lds[kBlock / 64];
-    __shared__ ScanVal excl[kBlock];
-    ScanVal carry = sv_zero();
-    for (int64_t base = 0; base < ntiles; base += kBlock) {
-        const int64_t i = base + threadIdx.x;
-        const ScanVal v = i < ntiles ? tile_sum[i] : sv_zero();
-        ScanVal total;
-        const ScanVal inc = block_inclusive_scan(v, lds, total);
-        const ScanVal ex = block_exclusive_from_inclusive(inc, excl);
-        if (i < ntiles) tile_sum[i] = sv_add(carry, ex);
-        carry = sv_add(carry, total);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_scan_apply(MomentSrc src, const int32_t *__restrict__ cnt,
-                                                       int64_t n, const ScanVal *__restrict__ tile_off,
-                                                       Moment *__restrict__ S, int32_t *__restrict__ Pex) {
-    __shared__ ScanVal lds[kBlock / 64];
-    __shared__ ScanVal excl[kBlock];
-    // The tile is swept in kScanItems rounds of kBlock consecutive elements: loads and the 68-byte stores are
-    // coalesced (a thread that owned 8 consecutive elements wrote at a 544-byte stride: 548 us at 10 M bodies).
-    // One block scan per round instead of one per tile - arithmetic is the cheap part here.
-    ScanVal carry = tile_off[blockIdx.x];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+__global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32_t *__restrict__ perm,
+                                                        const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
+                                                        int64_t n, double G, float4 *__restrict__ posm_s,
+                                                        double4 *__restrict__ p64_s /* may be null */, uint64_t *__restrict__ lo_s,
+                                                        int32_t *__restrict__ delta, double4 *__restrict__ S,
+                                                        int32_t *__restrict__ PexL, double4 *__restrict__ sub_tot,
+                                                        int32_t *__restrict__ sub_cnt) {
+    __shared__ Mom4 wtot[kBlock / 64];
+    __shared__ int dl[kBlock + 1];  // delta of the round's ranks, dl[0] = delta of the rank before the round
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 #pragma unroll 1
     for (int k = 0; k < kScanItems; k++) {
-        const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
-        const ScanVal v = sv_load(src, cnt, i, n);
-        ScanVal total;
-        const ScanVal inc = block_inclusive_scan(v, lds, total);
-        const ScanVal run = sv_add(carry, block_exclusive_from_inclusive(inc, excl));
-        if (i <= n) {  // entry n receives the grand totals
-            S[i] = Moment{run.m.h, run.m.l, run.x.h, run.x.l, run.y.h, run.y.l, run.z.h, run.z.l};
-            Pex[i] = run.c;
+        const int64_t r0 = (int64_t)blockIdx.x * kScanTile + (int64_t)k * kBlock;
+        if (r0 > n) break;  // entry n (the totals' slot) is the last one anybody reads
+        const int64_t r = r0 + t;
+        Mom4 v{0.0, 0.0, 0.0, 0.0, 0};
+        int d = -1;
+        uint64_t h = 0, l = 0;
+        if (r < n) {
+            const uint32_t j = perm[r];
+            const double x = cur.x[j], y = cur.y[j], z = cur.z[j], gm = G * cur.m[j];
+            posm_s[r] = make_float4((float)x, (float)y, (float)z, (float)gm);
+            if (p64_s) p64_s[r] = make_double4(x, y, z, gm);
+            h = hi_s[r];
+            l = key_lo[j];
+            lo_s[r] = l;
+            if (r + 1 < n) {
+                const uint64_t hn = hi_s[r + 1];
+                d = cpl_digits(h, l, hn, hn == h ? key_lo[perm[r + 1]] : 0ull);
+            }
+            delta[r] = d;
+            v = Mom4{gm, gm * x, gm * y, gm * z, 0};
         }
-        carry = sv_add(carry, total);
+        dl[t + 1] = d;
+        if (t == 0) {
+            int dp = -1;
+            if (r > 0 && r < n) {
+                const uint64_t hp = hi_s[r - 1];
+                dp = cpl_digits(hp, hp == h ? key_lo[perm[r - 1]] : 0ull, h, l);
+            }
+            dl[0] = dp;
+        }
+        __syncthreads();
+        if (r < n) {
+            const int dp = dl[t];
+            v.c = d > dp ? d - dp : 0;
+        }
+        // inclusive scan over the 256 ranks of the round
+        Mom4 inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const Mom4 u = m4_shfl_up(inc, o);
+            if (lane >= o) inc = m4_add(u, inc);
+        }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        Mom4 off{0.0, 0.0, 0.0, 0.0, 0}, tot{0.0, 0.0, 0.0, 0.0, 0};
+#pragma unroll
+        for (int q = 0; q < kBlock / 64; q++) {
+            if (q < w) off = m4_add(off, wtot[q]);
+            tot = m4_add(tot, wtot[q]);
+        }
+        inc = m4_add(off, inc);
+        if (r <= n) {
+            // exclusive = inclusive - own (own is exactly representable in the sum only for cnt; for the moments take
+            // the neighbour's inclusive value instead of subtracting)
+            Mom4 ex = m4_shfl_up(inc, 1);
+            if (lane == 0) ex = off;
+            S[r] = make_double4(ex.m, ex.x, ex.y, ex.z);
+            PexL[r] = ex.c;
+        }
+        if (t == 0) {
+            sub_tot[r0 >> kSubShift] = make_double4(tot.m, tot.x, tot.y, tot.z);
+            sub_cnt[r0 >> kSubShift] = tot.c;
+        }
+        __syncthreads();  // wtot / dl are reused by the next round
+    }
+}
+
+// Exclusive prefixes over the sub-tile totals: T (double-double moments, 64 bytes) and subPex.  One workgroup of
+// 1024 threads: a thread adds up a contiguous chunk, the chunk sums are scanned across the workgroup, a second
+// sweep writes the prefixes.  (39 k sub-tiles at 10 M bodies: 1.6 MB in, 2.7 MB out.)
+constexpr int kSubScanThreads = 1024;
+struct SubVal {
+    dd m, x, y, z;
+    long long c;
+};
+__device__ __forceinline__ SubVal sub_add(const SubVal &a, const SubVal &b) {
+    return SubVal{dd_add(a.m, b.m), dd_add(a.x, b.x), dd_add(a.y, b.y), dd_add(a.z, b.z), a.c + b.c};
+}
+__device__ __forceinline__ SubVal sub_zero() { return SubVal{{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, 0}; }
+__device__ __forceinline__ dd dd_shfl_up(const dd &v, int d) { return dd{__shfl_up(v.h, d), __shfl_up(v.l, d)}; }
+__device__ __forceinline__ SubVal sub_shfl_up(const SubVal &v, int d) {
+    return SubVal{dd_shfl_up(v.m, d), dd_shfl_up(v.x, d), dd_shfl_up(v.y, d), dd_shfl_up(v.z, d), __shfl_up(v.c, d)};
+}
+__global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4 *__restrict__ sub_tot,
+                                                                   const int32_t *__restrict__ sub_cnt, int64_t nsub,
+                                                                   Moment *__restrict__ T, int32_t *__restrict__ subPex) {
+    __shared__ SubVal wsum[kSubScanThreads / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t chunk = (nsub + kSubScanThreads - 1) / kSubScanThreads;
+    const int64_t b = (int64_t)t * chunk, e = b + chunk < nsub ? b + chunk : nsub;
+    SubVal acc = sub_zero();
+    for (int64_t i = b; i < e; i++) {
+        const double4 q = sub_tot[i];
+        acc = sub_add(acc, SubVal{{q.x, 0.0}, {q.y, 0.0}, {q.z, 0.0}, {q.w, 0.0}, (long long)sub_cnt[i]});
+    }
+    SubVal inc = acc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const SubVal u = sub_shfl_up(inc, o);
+        if (lane >= o) inc = sub_add(u, inc);
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    SubVal off = sub_zero();
+    for (int q = 0; q < w; q++) off = sub_add(off, wsum[q]);
+    SubVal run = sub_shfl_up(inc, 1);
+    if (lane == 0) run = sub_zero();
+    run = sub_add(off, run);  // exclusive prefix of this thread's chunk
+    for (int64_t i = b; i < e; i++) {
+        T[i] = Moment{run.m.h, run.m.l, run.x.h, run.x.l, run.y.h, run.y.l, run.z.h, run.z.l};
+        subPex[i] = (int32_t)run.c;
+        const double4 q = sub_tot[i];
+        run = sub_add(run, SubVal{{q.x, 0.0}, {q.y, 0.0}, {q.z, 0.0}, {q.w, 0.0}, (long long)sub_cnt[i]});
     }
 }
 
@@ -518,67 +529,182 @@ __device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
 }
 
 // ---------------------------------------------------------------------------------------
-// K8: emit nodes in DFS pre-order.  Pre-order index of a node "started" by sorted body r:
-// internal cell k of r (levels dp+1+k, k < cnt[r]) -> r + Pex[r] + k, leaf of r -> r + Pex[r+1].
-//   k_emit_leaves  one thread per body: writes the leaf, lists the body's internal cells
-//                  (cell q = Pex[r] + k  ->  cell_r[q] = r, cell_lev[q]), sentinel, max depth.
-//   k_emit_cells   one thread per internal cell q (Karras-style, uniform work per thread): finds
-//                  the cell's last body by galloping + binary search on the sorted keys, takes
-//                  mass / COM from the float64 prefix sums and writes node r + q.
-// (A thread-per-body loop over its cells made every wave as slow as its unluckiest lane.)
+// K8 [r3]: emit the nodes in DFS pre-order, one workgroup per tile of kEmitTile sorted ranks.
+// Pre-order index of a node "started" by sorted body r (dp = delta[r-1], d = delta[r], cnt = max(0, d - dp)):
+//   internal cell k of r (level dp+1+k, k < cnt) -> r + pex(r) + k,     leaf of r -> r + pex(r) + cnt.
+// A cell (r, lev) holds the bodies [r, e), e - 1 = the first j >= r with delta[j] < lev ("nearest smaller value to
+// the right").  Round 2 found e with a gallop + binary search on the sorted KEYS in global memory, one thread per
+// cell: ~2 log2(size) dependent 16-byte probes each, 527 us at 10 M bodies (64 % of the wave cycles parked at
+// s_waitcnt).  Now the tile's delta values sit in LDS as bytes under a min-tree (heap layout); the query "first
+// j >= r with delta[j] < lev" climbs from leaf r to the first subtree on its right whose minimum is small enough
+// and descends to its leftmost such leaf - a handful of LDS byte reads for the small cells that make up the
+// bulk.  Only cells that reach beyond their tile (<= depth of the tree per tile boundary) fall back to the key
+// search, started at the tile's end.  The same workgroup writes the leaves and lists the tile's cells in LDS
+// (chunks of kCellChunk), so the cell list never travels through global memory.
+// Mass / centre of mass of [r, e): see K5-K7.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_emit_leaves(const int32_t *__restrict__ delta, const int32_t *__restrict__ Pex,
-                                                        const float4 *__restrict__ posm_s, int64_t n, int64_t capacity,
-                                                        Node *__restrict__ nodes, uint8_t *__restrict__ node_level,
-                                                        int32_t *__restrict__ node_ref, int32_t *__restrict__ cell_r,
-                                                        uint8_t *__restrict__ cell_lev, double eps, TreeInfo *info,
-                                                        const double4 *__restrict__ p64_s = nullptr,
-                                                        double4 *__restrict__ diag64 = nullptr) {
-    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (r < n) {
-        const int64_t total = n + (int64_t)Pex[n];
-        if (r == 0) {
-            info->num_nodes = total;
-            info->walk_nodes = total;
-            info->band2 = 2u * band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
-        }
+constexpr int kEmitTile = 2048;
+constexpr int kCellChunk = 4096;
+
+__device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t *__restrict__ node_ref, int64_t total) {
+    Node sn;
+    sn.cx = sn.cy = sn.cz = 1.0e30f;
+    sn.gm = 0.f; sn.s2t = 0.f;
+    sn.next_off = (unsigned)total * kNodeBytes;
+    nodes[total] = sn;
+    node_ref[total] = -1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict__ delta, const int32_t *__restrict__ PexL,
+                                                      const int32_t *__restrict__ subPex, const double4 *__restrict__ S,
+                                                      const Moment *__restrict__ T, const float4 *__restrict__ posm_s,
+                                                      const double4 *__restrict__ p64_s, const uint64_t *__restrict__ hi_s,
+                                                      const uint64_t *__restrict__ lo_s, int64_t n, int64_t capacity,
+                                                      double eps, double inv_theta2, Node *__restrict__ nodes,
+                                                      Node64 *__restrict__ nodes64, uint8_t *__restrict__ node_level,
+                                                      int32_t *__restrict__ node_ref, double4 *__restrict__ diag64,
+                                                      NodeD *__restrict__ nodesd /* may be null */, Bodies cur,
+                                                      const uint32_t *__restrict__ perm, double G, TreeInfo *info) {
+    __shared__ uint8_t tree[2 * kEmitTile];   // heap: tree[kEmitTile + i] = delta[base + i] + 1, inner nodes = min of children
+    __shared__ uint8_t dprev;                 // delta[base - 1] + 1
+    __shared__ uint32_t cells[kCellChunk];    // (local body index << 8) | level
+    const int t = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kEmitTile;
+    const int64_t total = n + pex_at(PexL, subPex, n);
+    if (blockIdx.x == 0 && t == 0) {
+        info->num_nodes = total;
+        info->walk_nodes = total;
+        info->band2 = 2u * band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
         if (total + 1 > capacity) {  // + 1: the sentinel
-            if (r == 0) {
-                info->error = 1;
-                if (info->sticky_error == 0) {
-                    info->sticky_error = 1;
-                    info->sticky_nodes = total;
-                }
+            info->error = 1;
+            if (info->sticky_error == 0) {
+                info->sticky_error = 1;
+                info->sticky_nodes = total;
             }
         } else {
-            const int d = delta[r];
-            const int dp = r > 0 ? delta[r - 1] : -1;
+            write_sentinel(nodes, node_ref, total);
+            if (nodesd) nodesd[total] = NodeD{1.0e30, 1.0e30, 1.0e30, 0.0, 0.0f, (unsigned)total * kNodeDBytes};
+        }
+    }
+    if (total + 1 > capacity) return;
+    // delta of the tile as bytes (ranks >= n - 1 count as -1: nothing reaches across the end of the array)
+    for (int i = t; i < kEmitTile; i += kBlock) {
+        const int64_t r = base + i;
+        tree[kEmitTile + i] = (uint8_t)((r < n ? delta[r] : -1) + 1);
+    }
+    if (t == 0) dprev = (uint8_t)((base > 0 ? delta[base - 1] : -1) + 1);
+    __syncthreads();
+    for (int width = kEmitTile / 2; width >= 1; width >>= 1) {
+        for (int i = t; i < width; i += kBlock) {
+            const uint8_t a = tree[2 * (width + i)], b = tree[2 * (width + i) + 1];
+            tree[width + i] = a < b ? a : b;
+        }
+        __syncthreads();
+    }
+    const int64_t q_tile = pex_at(PexL, subPex, base < n ? base : n);
+    const int64_t tile_end = base + kEmitTile < n ? base + kEmitTile : n;
+    const int64_t ncell = pex_at(PexL, subPex, tile_end) - q_tile;  // cells started inside this tile
+    const double bounds = info->bounds;
+    const unsigned bandk = band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
+    for (int64_t c0 = 0; c0 == 0 || c0 < ncell; c0 += kCellChunk) {
+        // one thread per body: the leaf (first chunk only) and the body's cells that fall into this chunk
+        for (int i = t; i < kEmitTile; i += kBlock) {
+            const int64_t r = base + i;
+            if (r >= n) break;
+            const int d = (int)tree[kEmitTile + i] - 1;
+            const int dp = (int)(i > 0 ? tree[kEmitTile + i - 1] : dprev) - 1;
             const int cnt = d > dp ? d - dp : 0;
-            const int64_t q0 = Pex[r];
-            for (int k = 0; k < cnt; k++) {
-                cell_r[q0 + k] = (int32_t)r;
-                cell_lev[q0 + k] = (uint8_t)(dp + 1 + k);
+            const int64_t q0 = pex_at(PexL, subPex, r);
+            if (c0 == 0) {
+                const int64_t idx = r + q0 + cnt;
+                const float4 p = posm_s[r];
+                Node lf;
+                lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
+                lf.s2t = 0.0f;
+                lf.next_off = (unsigned)(idx + 1) * kNodeBytes;
+                nodes[idx] = lf;
+                if (diag64) diag64[idx] = p64_s ? p64_s[r] : make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
+                if (nodesd) {  // the body as the float64 state has it (nearly sequential: the state is in last step's key order)
+                    const uint32_t j = perm[r];
+                    nodesd[idx] = NodeD{cur.x[j], cur.y[j], cur.z[j], G * cur.m[j], 0.0f, (unsigned)(idx + 1) * kNodeDBytes};
+                }
+                node_ref[idx] = (int32_t)r;
+                node_level[idx] = (uint8_t)((d > dp ? d : dp) + 1);
             }
-            const int64_t idx = r + q0 + cnt;
-            const float4 p = posm_s[r];
-            const int leaf_level = (d > dp ? d : dp) + 1;
-            Node lf;
-            lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
-            lf.s2t = 0.0f;
-            lf.next_off = (unsigned)(idx + 1) * kNodeBytes;
-            nodes[idx] = lf;
-            if (diag64) diag64[idx] = p64_s ? p64_s[r] : make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
-            node_ref[idx] = (int32_t)r;
-            node_level[idx] = (uint8_t)leaf_level;
-            if (r == 0) {
-                Node sn;
-                sn.cx = sn.cy = sn.cz = 1.0e30f;
-                sn.gm = 0.f; sn.s2t = 0.f;
-                sn.next_off = (unsigned)total * kNodeBytes;
-                nodes[total] = sn;
-                node_ref[total] = -1;
+            for (int k = 0; k < cnt; k++) {
+                const int64_t c = q0 - q_tile + k - c0;
+                if (c >= 0 && c < kCellChunk) cells[c] = ((uint32_t)i << 8) | (uint32_t)(dp + 1 + k);
             }
         }
+        __syncthreads();
+        const int64_t here = ncell - c0 < kCellChunk ? ncell - c0 : kCellChunk;
+        for (int64_t c = t; c < here; c += kBlock) {
+            const uint32_t cl = cells[c];
+            const int i = (int)(cl >> 8), lev = (int)(cl & 255u);
+            const int64_t r = base + i;
+            // first local index j >= i with delta[j] + 1 <= lev
+            unsigned h = (unsigned)(kEmitTile + i);
+            bool found = false;
+            for (;;) {
+                if ((int)tree[h] <= lev) { found = true; break; }
+                while ((h & 1u) && h > 1u) h >>= 1;
+                if (h == 1u) break;
+                h += 1u;
+            }
+            int64_t e;
+            if (found) {
+                while (h < (unsigned)kEmitTile) {
+                    h <<= 1;
+                    if ((int)tree[h] > lev) h += 1u;
+                }
+                e = base + (int64_t)(h - (unsigned)kEmitTile) + 1;
+            } else {
+                // the cell reaches beyond the tile: gallop + binary search on the sorted keys from the tile's end on
+                const uint64_t kh = hi_s[r], kl = lo_s[r];
+                int64_t ok = base + kEmitTile - 1, bad, step = 1;
+                for (;;) {
+                    const int64_t u = ok + step;
+                    if (u >= n) { bad = n; break; }
+                    if (cpl_digits(kh, kl, hi_s[u], lo_s[u]) >= lev) { ok = u; step <<= 1; }
+                    else { bad = u; break; }
+                }
+                while (bad - ok > 1) {
+                    const int64_t mid = ok + ((bad - ok) >> 1);
+                    if (cpl_digits(kh, kl, hi_s[mid], lo_s[mid]) >= lev) ok = mid; else bad = mid;
+                }
+                e = bad;
+            }
+            // moments of [r, e)
+            const double4 s0 = S[r], s1 = S[e];
+            double M = s1.x - s0.x, mx = s1.y - s0.y, my = s1.z - s0.z, mz = s1.w - s0.w;
+            const int64_t ur = r >> kSubShift, ue = e >> kSubShift;
+            if (ue != ur) {
+                const Moment a = T[ur], b = T[ue];
+                M += dd_diff(dd{b.m, b.ml}, dd{a.m, a.ml});
+                mx += dd_diff(dd{b.x, b.xl}, dd{a.x, a.xl});
+                my += dd_diff(dd{b.y, b.yl}, dd{a.y, a.yl});
+                mz += dd_diff(dd{b.z, b.zl}, dd{a.z, a.zl});
+            }
+            double cx = 0.0, cy = 0.0, cz = 0.0;
+            if (M > 0.0) { cx = mx / M; cy = my / M; cz = mz / M; }
+            const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
+            const int64_t idx = r + q_tile + c0 + c;
+            Node nd;
+            nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
+            nd.gm = (float)M;  // the moments are sums of G*m
+            // upper edge of the uncertainty band: bits((2 hs)^2 / theta^2) + K  (theta == 0: +inf, never accepted)
+            const float s2t = (float)(size * size * inv_theta2);
+            nd.s2t = __int_as_float(__float_as_int(s2t) + (int)bandk);
+            const int64_t nxt = e + pex_at(PexL, subPex, e);
+            nd.next_off = (unsigned)nxt * kNodeBytes;
+            nodes[idx] = nd;
+            if (nodesd) nodesd[idx] = NodeD{cx, cy, cz, M, nd.s2t, (unsigned)nxt * kNodeDBytes};
+            nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
+            if (diag64) diag64[idx] = make_double4(cx, cy, cz, M);
+            node_ref[idx] = (int32_t)r;
+            node_level[idx] = (uint8_t)lev;
+        }
+        __syncthreads();
     }
 }
 
@@ -604,72 +730,16 @@ __global__ __launch_bounds__(kBlock) void k_max_level(const int32_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_emit_cells(const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ lo_s,
-                                                       const int32_t *__restrict__ Pex, const Moment *__restrict__ S,
-                                                       const int32_t *__restrict__ cell_r, const uint8_t *__restrict__ cell_lev,
-                                                       int64_t n, double eps, double inv_theta2, int64_t capacity,
-                                                       Node *__restrict__ nodes, Node64 *__restrict__ nodes64,
-                                                       uint8_t *__restrict__ node_level,
-                                                       int32_t *__restrict__ node_ref, const TreeInfo *__restrict__ info,
-                                                       double4 *__restrict__ diag64 = nullptr) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t ncells = Pex[n];
-    if (q >= ncells || n + ncells + 1 > capacity) return;
-    const int64_t r = cell_r[q];
-    const int lev = cell_lev[q];
-    const uint64_t h = hi_s[r], l = lo_s[r];
-    // largest j with cpl(r, j) >= lev (j = r qualifies); e = j + 1
-    int64_t ok = r, bad;
-    int64_t step = 1;
-    for (;;) {
-        const int64_t t = r + step;
-        if (t >= n) { bad = n; break; }
-        if (cpl_digits(h, l, hi_s[t], lo_s[t]) >= lev) { ok = t; step <<= 1; }
-        else { bad = t; break; }
-    }
-    while (bad - ok > 1) {
-        const int64_t mid = ok + ((bad - ok) >> 1);
-        if (cpl_digits(h, l, hi_s[mid], lo_s[mid]) >= lev) ok = mid; else bad = mid;
-    }
-    const int64_t e = bad;
-    const Moment s0 = S[r], s1 = S[e];
-    const double M = dd_diff(dd{s1.m, s1.ml}, dd{s0.m, s0.ml});
-    double cx = 0.0, cy = 0.0, cz = 0.0;
-    if (M > 0.0) {
-        cx = dd_diff(dd{s1.x, s1.xl}, dd{s0.x, s0.xl}) / M;
-        cy = dd_diff(dd{s1.y, s1.yl}, dd{s0.y, s0.yl}) / M;
-        cz = dd_diff(dd{s1.z, s1.zl}, dd{s0.z, s0.zl}) / M;
-    }
-    const double bounds = info->bounds;
-    const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
-    const int64_t idx = r + q;
-    Node nd;
-    nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
-    nd.gm = (float)M;  // the moments are sums of G*m
-    // upper edge of the uncertainty band: bits((2 hs)^2 / theta^2) + K  (theta == 0: +inf, never accepted)
-    const float s2t = (float)(size * size * inv_theta2);
-    nd.s2t = __int_as_float(__float_as_int(s2t) + (int)band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps));
-    nd.next_off = (unsigned)(e + (int64_t)Pex[e]) * kNodeBytes;
-    nodes[idx] = nd;
-    nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
-    if (diag64) diag64[idx] = make_double4(cx, cy, cz, M);
-    node_ref[idx] = (int32_t)r;
-    node_level[idx] = (uint8_t)lev;
-}
-
 // ---------------------------------------------------------------------------------------
-// K8b: child table.  Row i of an internal cell holds the byte offsets of its (up to 8) children in pre-order
-// (0 = no more children; offset 0 is the root and never a child).  The stack walk (k_walk_stack) expands a
-// cell with one 32-byte load of this row instead of following the sibling links one dependent load at a time.
-// One thread per internal cell, after all nodes exist: first child = next row, siblings via the skip links.
+// K8b: child table (stack-walk prototype only).  Row i of an internal cell holds the byte offsets of its (up to
+// 8) children in pre-order (0 = no more children; offset 0 is the root and never a child).  One thread per node
+// row, after all nodes exist: first child = next row, siblings via the skip links.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_child_table(const Node *__restrict__ nodes, const int32_t *__restrict__ Pex,
-                                                        const int32_t *__restrict__ cell_r, int64_t n, int64_t capacity,
-                                                        uint32_t *__restrict__ child_tab) {
-    const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t ncells = Pex[n];
-    if (q >= ncells || n + ncells + 1 > capacity) return;
-    const int64_t idx = (int64_t)cell_r[q] + q;
+__global__ __launch_bounds__(kBlock) void k_child_table(const Node *__restrict__ nodes, const TreeInfo *__restrict__ info,
+                                                        int64_t capacity, uint32_t *__restrict__ child_tab) {
+    const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (info->error || idx >= info->num_nodes || idx >= capacity) return;
+    if (__float_as_int(nodes[idx].s2t) == 0) return;  // a leaf
     const unsigned end = nodes[idx].next_off;
     unsigned c = (unsigned)(idx + 1) * kNodeBytes;
     uint32_t t[8];
@@ -719,6 +789,8 @@ struct WalkParams {
     double dt, damping;
     int curbuf;  // which of WalkTable.buf holds the current state
     int acc64;   // measurement (counted walk only, NBMI_ACC64=1): every visit's contribution summed in float64
+    int force_prec;  // 0 = per wave by local density (see k_walk), 1 = fp32 pair forces everywhere, 2 = float64 everywhere
+    float prec_tau;  // force_prec 0: a wave takes float64 when G rho dt^2 of its bodies exceeds this
     int prec;    // measurement (k_walk_diag, NBMI_PREC=<mode>): which visits compute their force in which arithmetic
     float near2; // k_walk_diag: "near" visits have fp32 dist_sq below this
 };
@@ -730,7 +802,8 @@ struct WalkParams {
 struct WalkTable {
     Bodies buf[2];
     const Node64 *n64;
-    const int32_t *pex;  // leaf of the body at sorted rank r = node r + pex[r + 1]
+    const NodeD *nodesd;  // float64 node records (null: the handle computes every force in fp32)
+    const int32_t *pex, *subpex;  // leaf of the body at sorted rank r = node r + pex_at(pex, subpex, r + 1)
     unsigned long long *maxabs_next;  // TreeInfo::maxabs_next
     double theta, eps2;
 };
@@ -743,15 +816,16 @@ struct Body64 {
 };
 
 // the reference's own test in float64 (simulation.py:249-258), operation for operation
-__device__ __forceinline__ bool exact_take(unsigned off, const Body64 &b) {
+__device__ __forceinline__ bool exact_take_idx(unsigned idx, const Body64 &b) {
     const WalkTable *t = b.tab;
-    const Node64 c = t->n64[off / kNodeBytes];
+    const Node64 c = t->n64[idx];
     const Bodies &cur = t->buf[b.curbuf];
     const double dx = c.cx - cur.x[b.j], dy = c.cy - cur.y[b.j], dz = c.cz - cur.z[b.j];
     const double dist_sq = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)), t->eps2);
     const double dist = sqrt(dist_sq);
     return (c.hs * 2.0) / dist < t->theta;
 }
+__device__ __forceinline__ bool exact_take(unsigned off, const Body64 &b) { return exact_take_idx(off / kNodeBytes, b); }
 
 // One node visit (C++ form: counted / eps == 0 kernels, seek(), and the product walk's re-decision visits).
 // `off` is the cursor as a byte offset into the node array; `resume` likewise.  Returns the next cursor.
@@ -992,6 +1066,152 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
                  : NBMI_CLOBBERS, "s60", "s61", "s62", "s63", "s64", "s65", "s68", "s69", "s70", "s71", "s72", "s73");
 }
 
+// ---------------------------------------------------------------------------------------
+// [r3] The float64 visit.  Why it exists (scripts/gpu_prec_diag.py, profiles/r03_precision_modes.jsonl): at 1 M
+// bodies x 100 steps the position error against the float64 reference is made by fp32 pair arithmetic, and not by
+// its random roundings but by its SYSTEMATIC ones - G m rounded to fp32 (alone: max 6.6e-5 of the largest
+// coordinate), v_rsq_f32's one-ulp error pattern (alone: 9.5e-5), fp32-rounded coordinates of near pairs - which act
+// like a slightly different force law step after step on the bodies of the dense inner disk, where a difference,
+// once it flips an opening decision, cascades.  With the force of every accepted visit in float64 (same accepted
+// sets) the GPU follows the reference to 3e-14 over the 100 steps.  Same lock-step scheme as the fp32 loop, operands
+// of the 40-byte NodeD record in SGPR pairs:
+//   d = c - p, d2 = |d|^2 + eps^2 in float64;  the opening test on fp32(d2) against the same s2t / band as the fp32
+//   loop (fp32(d2) is within half an ulp of the true value: well inside what the band allows for, so the accepted
+//   sets are the reference's here too);  y0 = v_rsq_f32(fp32(d2)), e = 1 - d2 y0^2 (one FMA, exact to 1e-16),
+//   G m d2^(-3/2) = G m y0^3 (1 + 1.5 e) [+ O(e^2) = 1e-14];  three float64 FMAs into the sums.
+// 18 float64-rate + 4 fp32-rate vector instructions per visit (the fp32 visit: 16 fp32-rate).
+// ---------------------------------------------------------------------------------------
+#define NBMI_V64_X(CX, CY, CZ, GM, S2T, NXT, NEXT8, NEXT2, LOPEN, LJOIN) \
+    "v_cmpx_ge_u32_e64 s[58:59], %[off], %[resume]\n"          \
+    "s_waitcnt lgkmcnt(0)\n"                                   \
+    "v_add_f64 %[dx], " CX ", -%[px]\n"                        \
+    "v_add_f64 %[dy], " CY ", -%[py]\n"                        \
+    "v_add_f64 %[dz], " CZ ", -%[pz]\n"                        \
+    "v_fma_f64 %[d2], %[dx], %[dx], %[eps2]\n"                 \
+    "v_fma_f64 %[d2], %[dy], %[dy], %[d2]\n"                   \
+    "v_fma_f64 %[d2], %[dz], %[dz], %[d2]\n"                   \
+    "v_cvt_f32_f64_e32 %[d2f], %[d2]\n"                        \
+    "v_cmpx_lt_i32_e64 s[60:61], " S2T ", %[d2f]\n"            \
+    "s_andn2_b64 s[62:63], s[58:59], s[60:61]\n"               \
+    "s_cbranch_scc1 " LOPEN "f\n"                              \
+    "s_mov_b32 %[off], " NXT "\n"                              \
+    LJOIN ":\n"                                                \
+    "s_load_dwordx8 " NEXT8 ", %[base], %[off]\n"              \
+    "s_load_dwordx2 " NEXT2 ", %[base], %[off] offset:32\n"    \
+    "v_rsq_f32_e32 %[d2f], %[d2f]\n"                           \
+    "v_mov_b32_e32 %[resume], " NXT "\n"                       \
+    "v_cvt_f64_f32_e32 %[y0], %[d2f]\n"                        \
+    "v_mul_f64 %[t], %[d2], %[y0]\n"                           \
+    "v_mul_f64 %[w], " GM ", %[y0]\n"                          \
+    "v_fma_f64 %[t], -%[t], %[y0], 1.0\n"                      \
+    "v_mul_f64 %[w], %[w], %[y0]\n"                            \
+    "v_mul_f64 %[w], %[w], %[y0]\n"                            \
+    "v_mul_f64 %[t], %[w], %[t]\n"                             \
+    "v_fma_f64 %[w], %[c15], %[t], %[w]\n"                     \
+    "v_fma_f64 %[sx], %[dx], %[w], %[sx]\n"                    \
+    "v_fma_f64 %[sy], %[dy], %[w], %[sy]\n"                    \
+    "v_fma_f64 %[sz], %[dz], %[w], %[sz]\n"                    \
+    "s_mov_b64 exec, -1\n"
+#define NBMI_O64_X(S2T, LOPEN, LJOIN)                \
+    LOPEN ":\n"                                      \
+    "s_sub_u32 s66, " S2T ", %[band2]\n"             \
+    "s_mov_b64 exec, s[62:63]\n"                     \
+    "v_cmp_lt_i32_e64 s[64:65], s66, %[d2f]\n"       \
+    "s_mov_b64 exec, s[60:61]\n"                     \
+    "s_cmp_lg_u64 s[64:65], 0\n"                     \
+    "s_cbranch_scc1 7f\n"                            \
+    "s_add_u32 %[off], %[off], 40\n"                 \
+    "s_branch " LJOIN "b\n"
+#define NBMI_V64_A(LO, LJ) \
+    NBMI_V64_X("s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s44", "s45", "s[48:55]", "s[56:57]", LO, LJ)
+#define NBMI_V64_B(LO, LJ) \
+    NBMI_V64_X("s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s56", "s57", "s[36:43]", "s[44:45]", LO, LJ)
+
+// walks from `off` to the end of the NodeD array (4 visits per loop test, the sentinel absorbs the overshoot) or
+// until a near-tie stops it (which = 1, cursor on the tied node)
+__device__ __forceinline__ void walk4_asm64(const NodeD *nodesd, unsigned &off, unsigned end, double px, double py,
+                                            double pz, double eps2, unsigned band2, unsigned &resume, double &sx,
+                                            double &sy, double &sz, unsigned &which) {
+    double dx, dy, dz, d2, y0, t, w;
+    float d2f;
+    const double c15 = 1.5;
+    asm volatile("s_load_dwordx8 s[36:43], %[base], %[off]\n"
+                 "s_load_dwordx2 s[44:45], %[base], %[off] offset:32\n"
+                 "1:\n" NBMI_V64_A("21", "31") NBMI_V64_B("22", "32") NBMI_V64_A("23", "33") NBMI_V64_B("24", "34")
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc1 1b\n"
+                 "s_branch 9f\n"
+                 NBMI_O64_X("s44", "21", "31") NBMI_O64_X("s56", "22", "32") NBMI_O64_X("s44", "23", "33") NBMI_O64_X("s56", "24", "34")
+                 "7:\n"
+                 "s_mov_b64 exec, -1\n"
+                 "s_mov_b32 %[which], 1\n"
+                 "9:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [y0] "=&v"(y0), [t] "=&v"(t),
+                   [w] "=&v"(w), [d2f] "=&v"(d2f)
+                 : [base] "s"(nodesd), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [c15] "s"(c15),
+                   [end] "s"(end), [band2] "s"(band2)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+                   "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
+                   "s66", "vcc", "scc", "memory");
+}
+
+// one float64 visit in C++ with the float64 re-decision of the lanes inside the band (the asm loop stopped on this
+// node).  Operation for operation the asm visit: a body's sums do not depend on which of its visits came through here.
+__device__ __forceinline__ unsigned tie_visit64(const NodeD *nodesd, unsigned off, double qx, double qy, double qz,
+                                                double eps2, unsigned band2, const Body64 &b64, unsigned &resume,
+                                                double &sx, double &sy, double &sz) {
+    off = __builtin_amdgcn_readfirstlane(off);
+    const NodeD *np = reinterpret_cast<const NodeD *>(reinterpret_cast<const char *>(nodesd) + off);
+    const bool active = resume <= off;
+    bool geom;
+    {   // the decision first, in a scope of its own: the float64 re-test is register hungry, and nothing of the
+        // force arithmetic below needs to be alive across it (the pointer is laundered so that it is recomputed)
+        const double dx = np->cx - qx, dy = np->cy - qy, dz = np->cz - qz;
+        const float d2f = (float)__builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+        const int d2b = __float_as_int(d2f), hi = __float_as_int(np->s2t), lo = hi - (int)band2;
+        geom = hi < d2b;
+        if (active && !geom && lo < d2b) geom = (hi == 0) || exact_take_idx(off / kNodeDBytes, b64);
+    }
+    asm volatile("" : "+s"(np));
+    const NodeD nd = *np;
+    const double dx = nd.cx - qx, dy = nd.cy - qy, dz = nd.cz - qz;
+    const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, __builtin_fma(dx, dx, eps2)));
+    const float d2f = (float)d2;
+    const bool take = active && geom;
+    const double y0 = (double)__builtin_amdgcn_rsqf(d2f);
+    const double t = d2 * y0;
+    double w = nd.gm * y0;
+    const double e = __builtin_fma(-t, y0, 1.0);
+    w = w * y0;
+    w = w * y0;
+    const double k = w * e;
+    w = __builtin_fma(1.5, k, w);
+    if (take) {
+        sx = __builtin_fma(dx, w, sx); sy = __builtin_fma(dy, w, sy); sz = __builtin_fma(dz, w, sz);
+        resume = nd.next_off;
+    }
+    const unsigned long long any_open = __builtin_amdgcn_ballot_w64(active && !geom);
+    return __builtin_amdgcn_readfirstlane(any_open ? off + kNodeDBytes : nd.next_off);
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
 // everything a lane carries through a walk
 struct WalkCtx {
     const Node *nodes;
@@ -1119,7 +1339,44 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     double sx = 0.0, sy = 0.0, sz = 0.0;  // ... emptied into these every few trips (two-level sums, NBMI_FLUSH)
     double acc64x = 0.0, acc64y = 0.0, acc64z = 0.0;
 
-    if (!kCount && !kGuard) {
+    // [r3] force precision of this wave (see NBMI_V64_X).  force_prec 0: float64 where the bodies' own neighbourhood is
+    // dense enough that an error, once made, is amplified within a few hundred steps - G rho dt^2 of the wave's 64
+    // bodies (sum of G m over the volume of their bounding box, every edge at least one softening length) above
+    // prec_tau.  All lanes of a wave agree; which 64 ranks form a wave does not depend on the sharding.
+    bool use64 = false;
+    if (!kCount && !kGuard && kIntegrate && tab->nodesd && P.force_prec != 1) {
+        if (P.force_prec == 2) {
+            use64 = true;
+        } else {
+            const float big = 3.0e38f;
+            const float ex = wave_max_f(valid ? C.px : -big) - wave_min_f(valid ? C.px : big);
+            const float ey = wave_max_f(valid ? C.py : -big) - wave_min_f(valid ? C.py : big);
+            const float ez = wave_max_f(valid ? C.pz : -big) - wave_min_f(valid ? C.pz : big);
+            const float gm_sum = wave_sum_f(valid ? posm_s[rank].w : 0.f);
+            const float fl = sqrtf(P.eps2);
+            const float vol = fmaxf(ex, fl) * fmaxf(ey, fl) * fmaxf(ez, fl);
+            use64 = gm_sum * (float)(P.dt * P.dt) > P.prec_tau * vol;
+        }
+        use64 = __builtin_amdgcn_readfirstlane((int)use64) != 0;
+    }
+    if (use64) {
+        const NodeD *nodesd = tab->nodesd;
+        double qx = 0.0, qy = 0.0, qz = 0.0;
+        if (valid) {
+            const Bodies &cur = tab->buf[P.curbuf];
+            qx = cur.x[j]; qy = cur.y[j]; qz = cur.z[j];
+        }
+        const double eps2d = tab->eps2;
+        const unsigned nnd = frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeDBytes);
+        unsigned off = 0u;
+        while (off < nnd) {
+            unsigned which = 0u;
+            walk4_asm64(nodesd, off, nnd, qx, qy, qz, eps2d, C.band2, resume, sx, sy, sz, which);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (!__builtin_amdgcn_readfirstlane(which)) break;
+            off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, C.band2, C.b64, resume, sx, sy, sz);
+        }
+    } else if (!kCount && !kGuard) {
         if (nn && P.pair) {
             // two cursors: [0, mid) and [mid, nn); the second needs the lanes' state at mid (seek).
             // Where to cut: a wave spends ~40 % of its visits inside the 1/64 of the array around its own bodies
@@ -1131,7 +1388,7 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                 const int64_t r0 = P.rank_begin + (int64_t)lb * blockDim.x + wv * 64;
                 const int64_t rl = r0 + 64 < P.rank_end ? r0 + 64 : P.rank_end;  // the wave's bodies: [r0, rl)
                 const int64_t rm = r0 < rl ? r0 + (rl - r0) / 2 : 0;
-                const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + tab->pex[rm + 1]) * kNodeBytes);
+                const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + pex_at(tab->pex, tab->subpex, rm + 1)) * kNodeBytes);
                 mid = (r0 < rl && home > 0u && home < nn) ? home : mid;
             }
             // (each half sums into its own accumulator, added at the end: a body's result does not depend on how the two
@@ -1388,6 +1645,10 @@ __global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ n
 //   7  as 1 with fp32 running sums (no float64 accumulation at all)
 //   8  as 6, one Newton step on the reciprocal square root
 //   9  as 2 but G m rounded to fp32
+//   10 ... 14  as 2 with ONE quantity rounded to fp32: the coordinate differences / dist_sq / the reciprocal square
+//      root (v_rsq_f32) / [13: v_rsq_f32 seed + one Newton step in float64 - the candidate product form] / each
+//      contribution before it is added
+//   20 float64 (as 13) for the bodies inside the cylindrical radius NBMI_PREC_NEAR (length units), 1 for the others
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ nodes, const double4 *__restrict__ diag64,
                                                       const WalkTable *tab, const TreeInfo *info_in,
@@ -1428,15 +1689,32 @@ __global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ n
         const bool take = active && geom;
         if (take) {
             const bool leaf = hi == 0;
-            const bool use64 = mode == 2 || mode == 9 || (mode == 3 && leaf) || (mode == 4 && dist_sq < P.near2);
+            const double rc2 = (double)P.near2;  // modes >= 20: bodies inside this cylindrical radius^2 (x, z) take float64
+            const bool core = mode >= 20 && (qx * qx + qz * qz) < rc2;
+            const bool use64 = mode == 2 || (mode >= 9 && mode <= 14) || (mode == 3 && leaf) || (mode == 4 && dist_sq < P.near2) || core;
             if (use64) {
                 const double4 c = diag64[off / kNodeBytes];
-                const double ex = c.x - qx, ey = c.y - qy, ez = c.z - qz;
-                const double d2 = ex * ex + ey * ey + ez * ez + eps2d;
-                const double inv = 1.0 / sqrt(d2);
+                double ex = c.x - qx, ey = c.y - qy, ez = c.z - qz;
+                if (mode == 10) { ex = (double)(float)ex; ey = (double)(float)ey; ez = (double)(float)ez; }
+                double d2 = ex * ex + ey * ey + ez * ez + eps2d;
+                if (mode == 11) d2 = (double)(float)d2;
+                double inv;
+                if (mode == 12) {
+                    inv = (double)__builtin_amdgcn_rsqf((float)d2);
+                } else if (mode == 13 || mode >= 20) {  // fp32 seed + one Newton step in float64
+                    const double y0 = (double)__builtin_amdgcn_rsqf((float)d2);
+                    const double e = fma(-d2 * y0, y0, 1.0);
+                    inv = fma(0.5 * y0, e, y0);
+                } else {
+                    inv = 1.0 / sqrt(d2);
+                }
                 const double gm = mode == 9 ? (double)nd.gm : c.w;
                 const double f = gm * inv * inv * inv;
-                sx += ex * f; sy += ey * f; sz += ez * f;
+                if (mode == 14) {
+                    sx += (double)(float)(ex * f); sy += (double)(float)(ey * f); sz += (double)(float)(ez * f);
+                } else {
+                    sx += ex * f; sy += ey * f; sz += ez * f;
+                }
             } else {
                 float ex = dx, ey = dy, ez = dz;
                 if (mode == 5) {
@@ -2168,19 +2446,22 @@ struct nbmi_sim {
     // scratch
     uint64_t *key_hi = nullptr, *key_lo = nullptr, *hi_s = nullptr, *lo_s = nullptr;
     uint32_t *idx = nullptr, *perm = nullptr;
-    int32_t *delta = nullptr, *cnt = nullptr, *Pex = nullptr;
+    int32_t *delta = nullptr, *Pex = nullptr;  // Pex: exclusive prefix of the cell counts INSIDE a sub-tile (PexL)
+    int32_t *subPex = nullptr, *sub_cnt = nullptr;  // per sub-tile: exclusive prefix / total of the cell counts
     float4 *posm_s = nullptr;
-    double4 *p64_s = nullptr;  // float64 twin of posm_s (moment sums)
-    Moment *S = nullptr;
-    ScanVal *tile_sum = nullptr;
+    double4 *p64_s = nullptr;  // float64 twin of posm_s: owner mode (bounding boxes) and NBMI_PREC only
+    double4 *S = nullptr;      // in-sub-tile exclusive prefix of {G m, G m x, G m y, G m z}
+    double4 *sub_tot = nullptr;  // per sub-tile totals of the same
+    Moment *T = nullptr;         // per sub-tile exclusive prefix, double-double
     Node *nodes = nullptr;
     uint32_t *child_tab = nullptr;  // 8 child offsets per node row (stack walk)
     Node64 *nodes64 = nullptr;  // float64 twin rows of the internal cells (near-tie re-decision)
+    NodeD *nodesd = nullptr;    // float64 node records of every node (waves that compute forces in float64)
+    int force_prec = 0;         // 0 = per wave by local density, 1 = fp32 everywhere, 2 = float64 everywhere (NBMI_FORCE_PREC)
+    double prec_tau = 1.0e-5;   // force_prec 0: float64 where G rho dt^2 exceeds this (NBMI_PREC_TAU)
     WalkTable *wtab = nullptr;  // device copy of the walk's per-handle constants
     uint8_t *node_level = nullptr;
     int32_t *node_ref = nullptr;  // first body (sorted rank) of every node; queries only
-    int32_t *cell_r = nullptr;  // internal-cell list: first body and level
-    uint8_t *cell_lev = nullptr;
     int64_t node_capacity = 0;   // rows of the walk array (own tree + received trees)
     int64_t own_node_rows = 0;   // rows the handle's own tree may use
     TreeInfo *info = nullptr;  // device
@@ -2265,7 +2546,9 @@ int upload_walk_table(nbmi_sim *s) {
     t.buf[0] = s->buf[0];
     t.buf[1] = s->buf[1];
     t.n64 = s->nodes64;
+    t.nodesd = s->nodesd;
     t.pex = s->Pex;
+    t.subpex = s->subPex;
     t.maxabs_next = &s->info->maxabs_next;
     t.theta = s->theta;
     t.eps2 = s->softening * s->softening;
@@ -2343,34 +2626,26 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     std::swap(s->hi_s, s->key_hi);
     s->t_hi = s->hi_s;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
-    k_gather<<<nblocks(n_live), kBlock, 0, st>>>(cur, s->perm, s->hi_s, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s,
-                                                 s->delta, s->cnt);
+    // ranks 0 .. n_live: entry n_live is the slot of the totals
+    k_gather_scan<<<(int)((n_live + 1 + kScanTile - 1) / kScanTile), kBlock, 0, st>>>(
+        cur, s->perm, s->hi_s, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s, s->delta, s->S, s->Pex, s->sub_tot, s->sub_cnt);
     return 0;
 }
 
 int enqueue_global_tree(nbmi_sim *s) {
     const int64_t n = s->nt;
     hipStream_t st = s->stream;
-    // (delta / cnt of the n bodies: written by k_gather)
-    {
-        const int64_t ntiles = (n + 1 + kScanTile - 1) / kScanTile;  // n + 1: entry n receives the totals
-        // moments from the float64 state through the sort permutation; run exchange: from the fp32 records
-        const MomentSrc src{s->p64_s, s->t_posm};
-        k_scan_reduce<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum);
-        k_scan_tiles<<<1, kBlock, 0, st>>>(s->tile_sum, ntiles);
-        k_scan_apply<<<(int)ntiles, kBlock, 0, st>>>(src, s->cnt, n, s->tile_sum, s->S, s->Pex);
-    }
+    // (delta, the in-sub-tile prefixes S / PexL and the sub-tile totals: written by k_gather_scan)
+    const int64_t nsub = (n + 1 + kBlock - 1) / kBlock;  // sub-tiles that hold the entries 0 .. n
+    k_scan_subtiles<<<1, kSubScanThreads, 0, st>>>(s->sub_tot, s->sub_cnt, nsub, s->T, s->subPex);
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
-    k_emit_leaves<<<nblocks(n), kBlock, 0, st>>>(s->delta, s->Pex, s->t_posm, n, s->own_node_rows, s->nodes,
-                                                 s->node_level, s->node_ref, s->cell_r, s->cell_lev, s->softening, s->info,
-                                                 s->p64_s, s->diag64);
-    // one thread per internal cell; the count lives on the device, so launch for the row budget
-    k_emit_cells<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->t_hi, s->t_lo, s->Pex, s->S, s->cell_r, s->cell_lev,
-                                                                  n, s->softening, inv_theta2, s->own_node_rows, s->nodes,
-                                                                  s->nodes64, s->node_level, s->node_ref, s->info, s->diag64);
+    k_emit_tile<<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
+        s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
+        inv_theta2, s->nodes, s->nodes64, s->node_level, s->node_ref, s->diag64, s->nodesd, s->buf[s->curbuf], s->perm, s->G,
+        s->info);
     if (s->walk_stack)
-        k_child_table<<<nblocks(s->own_node_rows - n), kBlock, 0, st>>>(s->nodes, s->Pex, s->cell_r, n, s->own_node_rows, s->child_tab);
+        k_child_table<<<nblocks(s->own_node_rows), kBlock, 0, st>>>(s->nodes, s->info, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -2410,8 +2685,10 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
     P.curbuf = s->curbuf;
     P.acc64 = getenv("NBMI_ACC64") ? atoi(getenv("NBMI_ACC64")) : 0;
+    P.force_prec = s->nodesd ? s->force_prec : 1;
+    P.prec_tau = (float)s->prec_tau;
     P.prec = s->prec;
-    P.near2 = (float)(s->prec_near * s->prec_near * s->softening * s->softening);
+    P.near2 = s->prec >= 20 ? (float)(s->prec_near * s->prec_near) : (float)(s->prec_near * s->prec_near * s->softening * s->softening);
     if (integrate && s->prec && s->diag64 && !guard && !s->owner) {  // measurement only, see k_walk_diag
         k_walk_diag<<<(int)((cntr + kBlock - 1) / kBlock), kBlock, 0, st>>>(s->nodes, s->diag64, s->wtab, s->info, s->posm_s, s->perm, P);
         NBMI_HIP_CHECK(hipGetLastError());
@@ -2425,7 +2702,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     // fastest or within 5 % of it; beyond ~280 k bodies the one-wave walk wins
     int parts = 1;
     while (parts < 16 && tree_groups <= 4300 && tree_groups * parts * 2 <= s->split_max_waves) parts *= 2;
-    if (integrate && !guard && parts > 1) {
+    if (integrate && !guard && parts > 1 && P.force_prec != 2) {  // (the split walk is fp32 only)
 #define NBMI_SPLIT(KV) \
     k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P)
         if (parts == 2) NBMI_SPLIT(2);
@@ -2565,6 +2842,11 @@ static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_HILBERT")) s->hilbert = atoi(e) != 0;
     if (const char *e = getenv("NBMI_WALK_LANE")) s->walk_lane = atoi(e);
     if (const char *e = getenv("NBMI_WALK_STACK")) s->walk_stack = atoi(e);
+    if (const char *e = getenv("NBMI_FORCE_PREC")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) s->force_prec = v;
+    }
+    if (const char *e = getenv("NBMI_PREC_TAU")) s->prec_tau = atof(e);
     if (const char *e = getenv("NBMI_PREC")) s->prec = atoi(e);
     if (const char *e = getenv("NBMI_PREC_NEAR")) s->prec_near = atof(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {
@@ -2596,14 +2878,18 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         s->node_capacity = node_rows_for(c) + s->node_extra;
         const int64_t own_rows = node_rows_for(c);
         if (dev_alloc(s, &s->key_hi, c) || dev_alloc(s, &s->key_lo, c) || dev_alloc(s, &s->hi_s, c) ||
-            dev_alloc(s, &s->lo_s, c) || dev_alloc(s, &s->p64_s, c) || dev_alloc(s, &s->idx, c) || dev_alloc(s, &s->perm, c) ||
-            dev_alloc(s, &s->delta, c) || dev_alloc(s, &s->cnt, c + 1) || dev_alloc(s, &s->Pex, c + 1) ||
-            dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->tile_sum, (c + 1) / kScanTile + 2) ||
+            dev_alloc(s, &s->lo_s, c) || ((s->owner || s->prec) && dev_alloc(s, &s->p64_s, c)) || dev_alloc(s, &s->idx, c) ||
+            dev_alloc(s, &s->perm, c) || dev_alloc(s, &s->delta, c) || dev_alloc(s, &s->Pex, c + 1) ||
+            dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->sub_tot, (c + 1) / kBlock + 2) ||
+            dev_alloc(s, &s->sub_cnt, (c + 1) / kBlock + 2) || dev_alloc(s, &s->subPex, (c + 1) / kBlock + 2) ||
+            dev_alloc(s, &s->T, (c + 1) / kBlock + 2) ||
             dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
             (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
             (s->prec && dev_alloc(s, &s->diag64, own_rows)) ||
-            dev_alloc(s, &s->cell_r, own_rows - c) || dev_alloc(s, &s->cell_lev, own_rows - c))
+            (s->force_prec != 1 && !s->owner && s->softening > 1e-12 && s->node_capacity + 2 <= kMaxNodeDRows &&
+             dev_alloc(s, &s->nodesd, s->node_capacity + 2)) ||
+            false)
             return -2;
         s->own_node_rows = own_rows;
         s->tmp_sort_bytes = nbmi::sort_pairs_temp_bytes((size_t)c, 0, 63);
@@ -3450,6 +3736,28 @@ int nbmi_visible_points(nbmi_sim *s, const double *cam12, double tan_h, double t
         NBMI_HIP_CHECK(hipMemcpyAsync(out_col, d_col, (size_t)rows * 12, hipMemcpyDeviceToHost, st));
         NBMI_HIP_CHECK(hipStreamSynchronize(st));
     }
+    return 0;
+}
+
+int nbmi_set_force_precision(nbmi_sim *s, int mode, double tau) {
+    if (int rc = check_handle(s)) return rc;
+    if (mode < 0 || mode > 2 || (mode == 0 && !(tau >= 0.0))) {
+        nbmi::set_error("nbmi_set_force_precision: mode must be 0 (auto), 1 (fp32) or 2 (float64), tau >= 0");
+        return NBMI_ERR_ARG;
+    }
+    if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
+    if (mode != 1 && !s->nodesd) {
+        if (s->owner || !(s->softening > 1e-12) || s->node_capacity + 2 > kMaxNodeDRows) {
+            nbmi::set_error("nbmi_set_force_precision: float64 forces need softening > 0, at most %lld node rows and a handle that is not in owner mode",
+                            (long long)kMaxNodeDRows);
+            return NBMI_ERR_ARG;
+        }
+        if (dev_alloc(s, &s->nodesd, s->node_capacity + 2)) return NBMI_ERR_HIP;
+        if (int rc = upload_walk_table(s)) return rc;
+        s->tree_valid = false;
+    }
+    s->force_prec = mode;
+    if (mode == 0 && tau > 0.0) s->prec_tau = tau;
     return 0;
 }
 

@@ -270,6 +270,15 @@ class HIPBarnesHutSimulation(_HIPSimulation):
     def build_tree(self):
         _nat.check(self._lib.nbmi_build_tree(self._h), "nbmi_build_tree")
 
+    FORCE_PRECISION = {"auto": 0, "f32": 1, "f64": 2}
+
+    def set_force_precision(self, mode="auto", tau=0.0):
+        """Arithmetic of the pair forces: "auto" (default: float64 for the waves whose bodies sit densely enough that
+        G rho dt^2 > tau, fp32 elsewhere), "f32", "f64" (the reference's own arithmetic, nbody/simulation.py:246-268).
+        The accepted (body, node) sets are the reference's in every mode."""
+        _nat.check(self._lib.nbmi_set_force_precision(self._h, self.FORCE_PRECISION[mode], float(tau)),
+                   "nbmi_set_force_precision")
+
     def tree_stats(self, depth=True):
         """num_nodes as build_octree returns it, max depth, root half size (compute_bounds).
         depth=False skips the reduction kernel behind max_depth (one small D2H copy only)."""

@@ -136,7 +136,7 @@ def make_ic(dist_name, n, R, G):
 _THREADS = {}
 
 
-def cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=25.0):
+def cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=25.0, strict_too=False):
     """Oracle timed on host cores for a bounded sample (about 10-30 s of CPU work)."""
     from oracle import pyref
     try:  # local -march=native build of the fast variant; fall back to the shipped one
@@ -193,9 +193,53 @@ def cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=25.0):
             st.step(dt)
         t = time.perf_counter() - t0
     ph = st.phase_s / steps
-    return {"value": n * steps / t, "unit": "body-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full steps of the same {n}-body workload after 1 warm-up step "
-                      f"(serial build {ph[2]:.2f}s + {cores}-thread walk {ph[3]:.2f}s per step; -O3 -ffast-math)"}
+    out = {"value": n * steps / t, "unit": "body-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{steps} full steps of the same {n}-body workload after 1 warm-up step "
+                     f"(serial build {ph[2]:.2f}s + {cores}-thread walk {ph[3]:.2f}s per step; -O3 -ffast-math)"}
+    if strict_too:
+        # "and report a strict -O3 number" - the IEEE build (no fast-math, no contraction: the build
+        # that reproduces the reference's goldens bit for bit), same threads, one timed step after one warm-up
+        try:
+            Ls = pyref.lib(path=pyref.build(fast=False, out_dir="/tmp"))
+        except Exception:
+            Ls = pyref.lib(fast=False)
+        Ls.nbref_set_num_threads(cores)
+        ss = pyref.BHStepper(p, v, m, theta, G, eps, 1.0, cap=pyref.UNCAPPED, rows=4 * n + 4096, L=Ls)
+        ss.step(dt)
+        ks = max(1, min(3, int(8.0 / max(first, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(ks):
+            ss.step(dt)
+        ts = time.perf_counter() - t0
+        out["strict_value"] = n * ks / ts
+        out["strict_sample"] = f"{ks} steps, strict IEEE build (-O2 -ffp-contract=off, no fast-math), {cores} threads"
+    return out
+
+
+def frame_rates(sim, dt, n, substeps=5, frames=6):
+    """The reference's per-frame call pattern (tools/record.py:821-832: `substeps` x step, compute_colors, get_positions,
+    get_colors - the boundary hands host buffers over), timed end to end INCLUDING the device-to-host copies: raw
+    float32 frames (24 B per body) and the device-side int16 delta codec (12 B per body).  Never `value`."""
+    out = {"substeps": substeps, "frames_timed": frames}
+    for name in ("raw", "delta_i16"):
+        try:
+            if name == "delta_i16":
+                sim.compute_colors(15.0)
+                sim.frame_keyframe()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                sim.step_many(dt, substeps)
+                sim.compute_colors(15.0)
+                if name == "raw":
+                    sim.get_positions()
+                    sim.get_colors()
+                else:
+                    sim.frame_delta()
+            t = (time.perf_counter() - t0) / frames
+            out[name] = {"ms_per_frame": 1e3 * t, "body_steps_per_s": n * substeps / t}
+        except Exception as ex:  # a measurement extra must not cost the bench line
+            out[name] = {"error": repr(ex)}
+    return out
 
 
 def bench_boids(args, n, dt):
@@ -289,11 +333,12 @@ def bench_boids_slabs(args, n, dt, world, rank, dev):
     from boids.flock import generate_initial_state
     from boids.sharded import HipSlabEngine, SlabFlock
     from nbody.sharded import DistComm
-    from oracle import pyref  # parameter table only
+    import config.boids as bcfg
+    params = np.array([float(bcfg.BOIDS[k]) for k in bcfg.PARAM_ORDER], dtype=np.float64)
     np.random.seed(42)
-    pos, vel, col = generate_initial_state(n, 500.0, 25.0)
+    pos, vel, col = generate_initial_state(n, float(bcfg.BOIDS["bounds"]), float(bcfg.BOIDS["max_speed"]))
     with contextlib.redirect_stdout(sys.stderr):
-        eng = HipSlabEngine(pos, vel, col, pyref.boids_params(), rank, world, device=dev)
+        eng = HipSlabEngine(pos, vel, col, params, rank, world, device=dev)
     del pos, vel, col
     fl = SlabFlock(eng, rank, world, DistComm(dist, eng.device) if world > 1 else None)
 
@@ -330,6 +375,8 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         per_gpu = args.bodies_per_gpu
     if args.theta is not None:
         theta = args.theta
+    if args.dt is not None and workload == args.workload:
+        dt = args.dt
     # default workload: weak scaling (per_gpu bodies per rank).  Strong scaling (the same bodies in
     # total, sharded) for the direct N^2 kernel, whose work per body grows with N, and for
     # BASELINE config 4, which is "10 M bodies across the GPUs of one node".
@@ -450,9 +497,12 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
             out["roofline"] = {"bound": "fp32-valu", "kernel": "k_direct", "achieved": ach, "peak": 157.3,
                                "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None, "kernel_ms": walk_ms,
                                "interactions_per_s": n_total * n_total / (walk_ms * 1e-3)}
+        if method == "barnes_hut" and workload == args.workload:
+            out["frame_pcie"] = frame_rates(sim, dt, n_total)
         if not args.no_cpu_baseline:
             sim.close()
-            out["cpu_baseline"] = cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(p, v, m, theta, G, eps, dt, method, budget_s=cpu_budget_s,
+                                               strict_too=(workload == "galaxy_1m_bh"))
     with contextlib.suppress(Exception):
         sim.close()
     return out
@@ -468,6 +518,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-10m", action="store_true",
                     help="default run only: leave out the second object (north_star's N = 10 M on this one GPU)")
+    ap.add_argument("--dt", type=float, default=None,
+                    help="override the workload's step (the `4k_galaxy_1m` preset steps galaxy_1m_bh at 0.05 / 5 = 0.01)")
     ap.add_argument("--theta", type=float, default=None,
                     help="override the workload's opening angle (exploration; BASELINE's metric is theta = 0.5)")
     args = ap.parse_args()
@@ -514,7 +566,7 @@ def main():
     # fits the "few minutes" budget with its CPU baseline).  north_star's target is quoted at N = 10 M, which
     # also fits one GPU: the same measurement for the config-4 input rides along as a second object.
     plain_default = (world == 1 and not use_dist and args.workload == "galaxy_1m_bh" and not args.bodies_per_gpu
-                     and args.theta is None and not args.skip_10m)
+                     and args.theta is None and args.dt is None and not args.skip_10m)
     if plain_default:
         out["north_star_10m"] = measure_nbody(args, "collision_10m_bh", 1, 0, dev, False, min(args.steps, 10),
                                               min(args.warmup, 2), cpu_budget_s=10.0)

@@ -212,6 +212,16 @@ int nbmi_visible_points(nbmi_sim *sim, const double *cam12, double tan_h, double
  * only enqueue: for callers that issue their collective ON the handle's stream (nbmi_stream; e.g.
  * torch.cuda.ExternalStream), so that a step needs no host synchronisation at all. */
 int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
+
+/* Arithmetic of the Barnes-Hut pair forces (the accepted (body, node) sets are the reference's in every mode):
+ *   0  per wave of 64 key-adjacent bodies: float64 where G rho dt^2 of the wave's bodies exceeds `tau`
+ *      (default 1e-5; tau = 0 keeps the current value), fp32 elsewhere.  Default.  The reference computes in
+ *      float64 throughout (nbody/simulation.py:246-268); in the dense inner part of a system fp32's systematic
+ *      roundings are amplified to > 1e-4 of the largest coordinate within 100 steps.
+ *   1  fp32 everywhere (float64 sums): fastest.
+ *   2  float64 everywhere: follows the reference to ~1e-13 over 100 steps at 1 M bodies.
+ * Environment NBMI_FORCE_PREC / NBMI_PREC_TAU set the initial values. */
+int nbmi_set_force_precision(nbmi_sim *sim, int mode, double tau);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 

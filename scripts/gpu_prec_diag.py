@@ -48,4 +48,15 @@ for mode in modes:
                    "p9999": float(np.quantile(err.max(axis=1), 0.9999) / scale),
                    "n_over_1e-5": int((err.max(axis=1) / scale > 1e-5).sum()), "gpu_s": round(time.time() - t0, 2)}
             print(json.dumps(row), flush=True)
+            if s == steps and os.environ.get("WHERE"):
+                e = err.max(axis=1) / scale
+                r0 = np.hypot(p[:, 0], p[:, 2])  # cylindrical radius at t = 0 (the disk is thin in y)
+                bad = np.flatnonzero(e > 1e-5)
+                qs = [0.5, 0.9, 0.99, 1.0]
+                print(json.dumps({"mode": mode, "where": {"n_bad": int(bad.size), "r0_quantiles_bad": [float(np.quantile(r0[bad], q)) for q in qs] if bad.size else None,
+                                  "r0_quantiles_all": [float(np.quantile(r0, q)) for q in (0.01, 0.05, 0.1, 0.25, 0.5)],
+                                  "top10": [{"body": int(b), "err": float(e[b]), "r0": float(r0[b]), "r_now": float(np.hypot(ref[b, 0], ref[b, 2]))} for b in np.argsort(e)[-10:][::-1]],
+                                  "err_by_r0_bin": [{"r0_lt": float(hi), "n": int(((r0 >= lo) & (r0 < hi)).sum()), "max": float(e[(r0 >= lo) & (r0 < hi)].max()) if ((r0 >= lo) & (r0 < hi)).any() else 0.0,
+                                                     "p999": float(np.quantile(e[(r0 >= lo) & (r0 < hi)], 0.999)) if ((r0 >= lo) & (r0 < hi)).sum() > 1000 else None}
+                                                    for lo, hi in zip([0, 5, 10, 20, 40, 80, 160, 320, 640], [5, 10, 20, 40, 80, 160, 320, 640, 1e9])]}}), flush=True)
     del gpu

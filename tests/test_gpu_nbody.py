@@ -78,7 +78,7 @@ def test_accelerations(gpu, oracle, name, theta, key):
     _, st = oracle.compute_forces_barnes_hut(pos, mass, nd, nn, theta, float(g["G"]), float(g["eps"]), stats=True)
     wc = sim.walk_counters()
     print("   counters", wc, "oracle", st)
-    assert abs(wc["lane_accepts"] - st["accepted"]) <= max(2, 1e-4 * st["accepted"])
+    assert wc["lane_accepts"] == st["accepted"]  # ties are re-decided in float64: the sets are the reference's
     sim.close()
 
 
@@ -102,15 +102,14 @@ def test_extreme_theta(gpu, oracle, theta):
     wc = sim.walk_counters()
     print(f"theta={theta}: max err {err:.2e}, accepts {wc['lane_accepts']} vs {st['accepted']}, "
           f"visits/body {wc['lane_visits'] / len(pos):.1f}")
-    # coarse theta: a flipped tie costs one big cell's truncation error, hence the looser bound there
-    assert err <= (2e-4 if theta <= 1.0 else 5e-3)
-    assert abs(wc["lane_accepts"] - st["accepted"]) <= max(2, 2e-4 * st["accepted"])
+    assert err <= 1e-4
+    assert wc["lane_accepts"] == st["accepted"]
     if theta == 0.0:
         assert wc["lane_accepts"] == len(pos) * (len(pos) - 1) == st["accepted"]  # every other body, exactly
     o = oracle.BHStepper(pos, vel, mass, theta, G, eps, 1.0)
     o.step(0.05)
     sim.step(0.05)
-    tol = (2e-4 if theta <= 1.0 else 5e-3) * scale * 0.05 ** 2 + 1e-12
+    tol = 1e-4 * scale * 0.05 ** 2 + 1e-12
     assert np.abs(sim.get_positions_f64() - o.pos).max() <= tol
     import os
     os.environ["NBMI_SPLIT_WAVES"] = "0"
@@ -152,7 +151,7 @@ def test_every_walk_kernel_against_oracle(gpu, oracle, n, kernel):
     err = np.abs(got - ref).max() / (acc_scale * dt * dt)
     err_plain = np.abs(got - pl).max() / (acc_scale * dt * dt)
     print(f"{kernel} (n={n}): max acc-equivalent err vs oracle {err:.2e}, vs one-cursor loop {err_plain:.2e}")
-    assert err <= 5e-3            # one opening-test tie (section 5) at most
+    assert err <= 1e-4            # same accepted pairs as the oracle: only pair arithmetic differs
     assert np.quantile(np.abs(got - ref).max(axis=1), 0.999) / (acc_scale * dt * dt) <= 2e-5
     assert err_plain <= 1e-5      # same accepted pairs: only fp32 association differs
     assert sim.tree_stats()["num_nodes"] == o.num_nodes
@@ -562,6 +561,86 @@ def test_galaxy_200k_100_steps_meets_the_north_star_bound(gpu, oracle):
     sim.close()
 
 
+def _oracle_galaxy_1m(oracle, steps, keep):
+    """Oracle positions of BASELINE config 2 after the steps in `keep`: from tests/cache/ (scripts/oracle_traj_cache.py,
+    same strict-IEEE build: bit-identical on any x86 host) when the files travelled with the tree, else computed here
+    (about 2.3 s per step on 32 host threads)."""
+    import os
+    from conftest import ROOT
+    from tools.presets import generate_distribution
+    np.random.seed(42)
+    p, v, m = generate_distribution("galaxy", 1_000_000, 800.0, 0.07)
+    files = {k: os.path.join(ROOT, "tests", "cache", f"oracle_galaxy_1000000_step{k}.npy") for k in keep}
+    if all(os.path.exists(f) for f in files.values()):
+        print("  (oracle trajectory from tests/cache)")
+        return p, v, m, {k: np.load(f) for k, f in files.items()}
+    L = oracle.lib()
+    L.nbref_set_num_threads(min(32, int(L.nbref_num_threads())))
+    ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED, fast=False)
+    out = {}
+    for k in range(1, steps + 1):
+        ostep.step(0.05)
+        if k in keep:
+            out[k] = ostep.pos.copy()
+    return p, v, m, out
+
+
+def test_galaxy_1m_100_steps_meets_the_north_star_bound(gpu, oracle):
+    """BASELINE config 2 itself: galaxy, 1 M bodies, theta 0.5, dt 0.05, 100 steps against the float64 reference
+    algorithm; error relative to the largest coordinate.  north_star: <= 1e-4.  (Round 2 ended at 3.4e-4 with fp32
+    pair forces everywhere; the default now computes the dense waves' forces in float64)"""
+    p, v, m, ref = _oracle_galaxy_1m(oracle, 100, (10, 50, 100))
+    sim = _bh(gpu, p, v, m, 0.07, 1.5, theta=0.5)
+    for k in range(1, 101):
+        sim.step(0.05)
+        if k in ref:
+            d = np.abs(sim.get_positions_f64() - ref[k]).max(axis=1) / np.abs(ref[k]).max()
+            print(f"  1 M x {k} steps: max {d.max():.3e} p99.9 {np.quantile(d, 0.999):.3e} rms {np.sqrt((d ** 2).mean()):.3e}")
+    assert d.max() <= 1e-4
+    assert np.quantile(d, 0.999) <= 1e-5
+    sim.close()
+
+
+def test_force_precision_modes(gpu, oracle):
+    """nbmi_set_force_precision: "f64" follows the float64 reference to rounding level over 20 steps (the accepted sets
+    are the reference's and so is the arithmetic), "f32" to the fp32 level, "auto" lies between; all three build the
+    same octree.  200 k bodies (one-wave walk; the split walk of smaller systems is fp32 only unless "f64" is forced:
+    checked at 20 k)."""
+    from tools.presets import generate_distribution
+    n = 200_000
+    np.random.seed(7)
+    p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
+    m = m * np.random.uniform(0.5, 1.5, n)
+    ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED, fast=False)
+    for _ in range(20):
+        ostep.step(0.05)
+    scale = np.abs(ostep.pos).max()
+    err = {}
+    for mode in ("f64", "auto", "f32"):
+        sim = _bh(gpu, p, v, m, 0.07, 1.5, theta=0.5)
+        sim.set_force_precision(mode)
+        sim.step_many(0.05, 20)
+        err[mode] = np.abs(sim.get_positions_f64() - ostep.pos).max() / scale
+        assert sim.tree_stats()["num_nodes"] == ostep.num_nodes
+        sim.close()
+    print("force precision, 200 k x 20 steps, max rel position error:", err)
+    assert err["f64"] <= 1e-12
+    assert err["f64"] <= err["auto"] <= 1e-7
+    assert err["f32"] <= 1e-6
+    # small system (split-walk size): "f64" must take the float64 loop there too
+    k = 20_000
+    o2 = oracle.BHStepper(p[:k], v[:k], m[:k], 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED, fast=False)
+    s2 = _bh(gpu, p[:k], v[:k], m[:k], 0.07, 1.5, theta=0.5)
+    s2.set_force_precision("f64")
+    for _ in range(10):
+        o2.step(0.05)
+    s2.step_many(0.05, 10)
+    e2 = np.abs(s2.get_positions_f64() - o2.pos).max() / np.abs(o2.pos).max()
+    print("   20 k bodies, f64 forced, 10 steps:", e2)
+    assert e2 <= 1e-12
+    s2.close()
+
+
 def test_cluster_1m_direct_at_config_3_size(gpu, oracle):
     """BASELINE config 3 AT SIZE: 1 M-body Plummer cluster (device-side generator, accurate_cluster constants
     G 0.05, eps 1.0, R 300, dt 0.02), direct O(N^2).  Forces of a 4 096-body sample against the float64
@@ -629,7 +708,7 @@ def test_collision_10m_tree_vs_uncapped_oracle(gpu, oracle):
     err = _rel_err(acc[sample], acc2[:len(sample)])
     print(f"10M sample acc rel err max {err.max():.3e} median {np.median(err):.3e}; dropped pushes {stats[2]}")
     assert stats[2] == 0
-    assert np.median(err) <= 5e-6 and err.max() <= 5e-3
+    assert np.median(err) <= 5e-6 and err.max() <= 1e-4
     del sub_pos, ref, acc2, p2, m2
     sim.step(0.25)
     x = sim.get_positions_f64()
