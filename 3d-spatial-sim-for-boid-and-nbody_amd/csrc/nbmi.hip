@@ -341,27 +341,27 @@ __global__ __launch_bounds__(kBlock) void k_tiefix(const uint64_t *__restrict__ 
 
 // ---------------------------------------------------------------------------------------
 // K5 - K7 [r3]: ONE pass puts the bodies in key order and lays the ground for every cell's mass and centre of mass.
-// A workgroup owns a tile of kScanTile = 2048 sorted ranks, swept in 8 rounds of 256 consecutive ranks (a SUB-TILE):
+// A workgroup owns a tile (SUB-TILE of the prefix sums) of kScanTile = 2048 sorted ranks, swept in 8 rounds of 256:
 //   * gather through the sort permutation: fp32 {x,y,z,G m} (walk / leaf data), the low key word;
 //   * from the sorted keys of the two neighbours
 //       delta[r] = common prefix digits of sorted bodies r and r+1 (delta[N-1] = -1),
 //       cnt[r]   = number of internal cells whose first body is r = max(0, delta[r] - delta[r-1]);
-//   * exclusive prefix sums INSIDE the sub-tile (plain float64, straight from the float64 state):
+//   * exclusive prefix sums INSIDE the tile (plain float64, straight from the float64 state):
 //       S[r]    = sum over the sub-tile's bodies before r of {G m, G m x, G m y, G m z}     (32 bytes)
 //       PexL[r] = the same for cnt
 //     and the sub-tile's totals (sub_tot / sub_cnt).
 // k_scan_subtiles then turns the totals into exclusive prefixes over the sub-tiles (T: double-double, subPex).
 // A cell's moments are   (T[sub(e)] - T[sub(r)])  +  (S[e] - S[r])   for its body range [r, e):
-// the first difference is exact to 1e-32 (double-double), the second is between sums of at most 255 terms, so a
-// cell's centre of mass is good to ~1e-14 of the coordinate wherever the cell sits in the array.  (A plain float64
+// the first difference is exact to 1e-32 (double-double), the second is between sums of at most 2047 terms, so a
+// cell's centre of mass is good to ~1e-13 of the coordinate wherever the cell sits in the array.  (A plain float64
 // running sum over 10^6 bodies loses 1e-8, the size of the opening-test ties K9 re-decides in float64; round 2
 // carried double-double sums through a three-phase scan of 64-byte records instead - 1.0 GB more traffic at 10 M
 // bodies and three more kernels.)  Pre-order index helpers: pex_at(r) = subPex[r / 256] + PexL[r].
 // ---------------------------------------------------------------------------------------
 constexpr int kScanItems = 8;                      // rounds (sub-tiles) per workgroup
 constexpr int kScanTile = kBlock * kScanItems;     // 2048 ranks per workgroup
-constexpr int kSubShift = 8;                       // sub-tile = 256 ranks = one round
-static_assert(kBlock == (1 << kSubShift), "a sub-tile is one round of the workgroup");
+constexpr int kSubShift = 11;                      // sub-tile = the workgroup's 2048 ranks
+static_assert(kScanTile == (1 << kSubShift), "a sub-tile is one workgroup's tile");
 
 // double-double (unevaluated sum of two float64)
 struct dd {
@@ -403,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
     __shared__ Mom4 wtot[kBlock / 64];
     __shared__ int dl[kBlock + 1];  // delta of the round's ranks, dl[0] = delta of the rank before the round
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    Mom4 carry{0.0, 0.0, 0.0, 0.0, 0};  // the rounds before this one (plain float64: at most 2047 terms)
 #pragma unroll 1
     for (int k = 0; k < kScanItems; k++) {
         const int64_t r0 = (int64_t)blockIdx.x * kScanTile + (int64_t)k * kBlock;
@@ -449,13 +450,14 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
         }
         if (lane == 63) wtot[w] = inc;
         __syncthreads();
-        Mom4 off{0.0, 0.0, 0.0, 0.0, 0}, tot{0.0, 0.0, 0.0, 0.0, 0};
+        Mom4 off = carry, tot{0.0, 0.0, 0.0, 0.0, 0};
 #pragma unroll
         for (int q = 0; q < kBlock / 64; q++) {
             if (q < w) off = m4_add(off, wtot[q]);
             tot = m4_add(tot, wtot[q]);
         }
         inc = m4_add(off, inc);
+        carry = m4_add(carry, tot);
         if (r <= n) {
             // exclusive = inclusive - own (own is exactly representable in the sum only for cnt; for the moments take
             // the neighbour's inclusive value instead of subtracting)
@@ -464,11 +466,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
             S[r] = make_double4(ex.m, ex.x, ex.y, ex.z);
             PexL[r] = ex.c;
         }
-        if (t == 0) {
-            sub_tot[r0 >> kSubShift] = make_double4(tot.m, tot.x, tot.y, tot.z);
-            sub_cnt[r0 >> kSubShift] = tot.c;
-        }
         __syncthreads();  // wtot / dl are reused by the next round
+    }
+    if (t == 0) {
+        sub_tot[blockIdx.x] = make_double4(carry.m, carry.x, carry.y, carry.z);
+        sub_cnt[blockIdx.x] = carry.c;
     }
 }
 
@@ -552,7 +554,7 @@ __device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t
     sn.gm = 0.f; sn.s2t = 0.f;
     sn.next_off = (unsigned)total * kNodeBytes;
     nodes[total] = sn;
-    node_ref[total] = -1;
+    if (node_ref) node_ref[total] = -1;
 }
 
 __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict__ delta, const int32_t *__restrict__ PexL,
@@ -628,8 +630,10 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                     const uint32_t j = perm[r];
                     nodesd[idx] = NodeD{cur.x[j], cur.y[j], cur.z[j], G * cur.m[j], 0.0f, (unsigned)(idx + 1) * kNodeDBytes};
                 }
-                node_ref[idx] = (int32_t)r;
-                node_level[idx] = (uint8_t)((d > dp ? d : dp) + 1);
+                if (node_ref) {  // queries and the owner-mode kernels only: a plain step does not pay for them
+                    node_ref[idx] = (int32_t)r;
+                    node_level[idx] = (uint8_t)((d > dp ? d : dp) + 1);
+                }
             }
             for (int k = 0; k < cnt; k++) {
                 const int64_t c = q0 - q_tile + k - c0;
@@ -701,8 +705,10 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             if (nodesd) nodesd[idx] = NodeD{cx, cy, cz, M, nd.s2t, (unsigned)nxt * kNodeDBytes};
             nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
             if (diag64) diag64[idx] = make_double4(cx, cy, cz, M);
-            node_ref[idx] = (int32_t)r;
-            node_level[idx] = (uint8_t)lev;
+            if (node_ref) {
+                node_ref[idx] = (int32_t)r;
+                node_level[idx] = (uint8_t)lev;
+            }
         }
         __syncthreads();
     }
@@ -1079,7 +1085,7 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
 //   loop (fp32(d2) is within half an ulp of the true value: well inside what the band allows for, so the accepted
 //   sets are the reference's here too);  y0 = v_rsq_f32(fp32(d2)), e = 1 - d2 y0^2 (one FMA, exact to 1e-16),
 //   G m d2^(-3/2) = G m y0^3 (1 + 1.5 e) [+ O(e^2) = 1e-14];  three float64 FMAs into the sums.
-// 18 float64-rate + 4 fp32-rate vector instructions per visit (the fp32 visit: 16 fp32-rate).
+// 17 float64-rate + 4 fp32-rate vector instructions per visit (the fp32 visit: 16 fp32-rate).
 // ---------------------------------------------------------------------------------------
 #define NBMI_V64_X(CX, CY, CZ, GM, S2T, NXT, NEXT8, NEXT2, LOPEN, LJOIN) \
     "v_cmpx_ge_u32_e64 s[58:59], %[off], %[resume]\n"          \
@@ -1101,13 +1107,12 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
     "v_rsq_f32_e32 %[d2f], %[d2f]\n"                           \
     "v_mov_b32_e32 %[resume], " NXT "\n"                       \
     "v_cvt_f64_f32_e32 %[y0], %[d2f]\n"                        \
-    "v_mul_f64 %[t], %[d2], %[y0]\n"                           \
+    "v_mul_f64 %[t], %[y0], %[y0]\n"                           \
     "v_mul_f64 %[w], " GM ", %[y0]\n"                          \
-    "v_fma_f64 %[t], -%[t], %[y0], 1.0\n"                      \
-    "v_mul_f64 %[w], %[w], %[y0]\n"                            \
-    "v_mul_f64 %[w], %[w], %[y0]\n"                            \
-    "v_mul_f64 %[t], %[w], %[t]\n"                             \
-    "v_fma_f64 %[w], %[c15], %[t], %[w]\n"                     \
+    "v_fma_f64 %[d2], -%[d2], %[t], 1.0\n"                     \
+    "v_mul_f64 %[w], %[w], %[t]\n"                             \
+    "v_mul_f64 %[d2], %[d2], %[c15]\n"                         \
+    "v_fma_f64 %[w], %[w], %[d2], %[w]\n"                      \
     "v_fma_f64 %[sx], %[dx], %[w], %[sx]\n"                    \
     "v_fma_f64 %[sy], %[dy], %[w], %[sy]\n"                    \
     "v_fma_f64 %[sz], %[dz], %[w], %[sz]\n"                    \
@@ -1181,13 +1186,12 @@ __device__ __forceinline__ unsigned tie_visit64(const NodeD *nodesd, unsigned of
     const float d2f = (float)d2;
     const bool take = active && geom;
     const double y0 = (double)__builtin_amdgcn_rsqf(d2f);
-    const double t = d2 * y0;
+    const double t = y0 * y0;
     double w = nd.gm * y0;
-    const double e = __builtin_fma(-t, y0, 1.0);
-    w = w * y0;
-    w = w * y0;
-    const double k = w * e;
-    w = __builtin_fma(1.5, k, w);
+    const double e = __builtin_fma(-d2, t, 1.0);
+    w = w * t;
+    const double h = e * 1.5;
+    w = __builtin_fma(w, h, w);
     if (take) {
         sx = __builtin_fma(dx, w, sx); sy = __builtin_fma(dy, w, sy); sz = __builtin_fma(dz, w, sz);
         resume = nd.next_off;
@@ -2632,18 +2636,19 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     return 0;
 }
 
-int enqueue_global_tree(nbmi_sim *s) {
+// aux: also write node_ref / node_level (cell queries, owner-mode kernels)
+int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
     const int64_t n = s->nt;
     hipStream_t st = s->stream;
     // (delta, the in-sub-tile prefixes S / PexL and the sub-tile totals: written by k_gather_scan)
-    const int64_t nsub = (n + 1 + kBlock - 1) / kBlock;  // sub-tiles that hold the entries 0 .. n
+    const int64_t nsub = (n + 1 + kScanTile - 1) / kScanTile;  // sub-tiles that hold the entries 0 .. n
     k_scan_subtiles<<<1, kSubScanThreads, 0, st>>>(s->sub_tot, s->sub_cnt, nsub, s->T, s->subPex);
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_tile<<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
         s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
-        inv_theta2, s->nodes, s->nodes64, s->node_level, s->node_ref, s->diag64, s->nodesd, s->buf[s->curbuf], s->perm, s->G,
-        s->info);
+        inv_theta2, s->nodes, s->nodes64, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
+        s->force_prec != 1 ? s->nodesd : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info);
     if (s->walk_stack)
         k_child_table<<<nblocks(s->own_node_rows), kBlock, 0, st>>>(s->nodes, s->info, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
@@ -2651,7 +2656,7 @@ int enqueue_global_tree(nbmi_sim *s) {
 }
 
 // Single-GPU build: the tree over the handle's own bodies.
-int enqueue_tree(nbmi_sim *s, int ev_base) {
+int enqueue_tree(nbmi_sim *s, int ev_base, bool aux = true) {
     if (s->owner) {
         nbmi::set_error("this handle is in owner mode: use the nbmi_owner_* calls");
         return NBMI_ERR_ARG;
@@ -2659,9 +2664,9 @@ int enqueue_tree(nbmi_sim *s, int ev_base) {
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
     if (int rc = enqueue_maxabs(s)) return rc;
     if (int rc = enqueue_local_sort(s, ev_base)) return rc;
-    if (int rc = enqueue_global_tree(s)) return rc;
+    if (int rc = enqueue_global_tree(s, aux)) return rc;
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[3], s->stream));
-    s->tree_valid = true;
+    s->tree_valid = aux;
     return 0;
 }
 
@@ -2880,9 +2885,9 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
         if (dev_alloc(s, &s->key_hi, c) || dev_alloc(s, &s->key_lo, c) || dev_alloc(s, &s->hi_s, c) ||
             dev_alloc(s, &s->lo_s, c) || ((s->owner || s->prec) && dev_alloc(s, &s->p64_s, c)) || dev_alloc(s, &s->idx, c) ||
             dev_alloc(s, &s->perm, c) || dev_alloc(s, &s->delta, c) || dev_alloc(s, &s->Pex, c + 1) ||
-            dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->sub_tot, (c + 1) / kBlock + 2) ||
-            dev_alloc(s, &s->sub_cnt, (c + 1) / kBlock + 2) || dev_alloc(s, &s->subPex, (c + 1) / kBlock + 2) ||
-            dev_alloc(s, &s->T, (c + 1) / kBlock + 2) ||
+            dev_alloc(s, &s->S, c + 1) || dev_alloc(s, &s->sub_tot, (c + 1) / kScanTile + 2) ||
+            dev_alloc(s, &s->sub_cnt, (c + 1) / kScanTile + 2) || dev_alloc(s, &s->subPex, (c + 1) / kScanTile + 2) ||
+            dev_alloc(s, &s->T, (c + 1) / kScanTile + 2) ||
             dev_alloc(s, &s->nodes, s->node_capacity + 2) || dev_alloc(s, &s->nodes64, s->node_capacity + 2) ||
             dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
             (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
@@ -3026,7 +3031,7 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
     for (int k = 0; k < substeps; k++) {
         if (s->method == NBMI_METHOD_BARNES_HUT) {
             const int evb = s->timers ? 0 : -1;
-            if (int rc = enqueue_tree(s, evb)) return rc;
+            if (int rc = enqueue_tree(s, evb, false)) return rc;
             if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
             if (s->timers) {
                 NBMI_HIP_CHECK(hipEventRecord(s->ev[4], s->stream));

@@ -80,7 +80,7 @@ WORKLOADS = {
 }
 
 
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def csrc_sha():
@@ -400,6 +400,8 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
             sim = (gb.HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta, device=dev) if method == "barnes_hut"
                    else gb.HIPDirectSimulation(p, v, m, G, eps, 1.0, device=dev))
             step = lambda k: sim.step_many(dt, k)  # noqa: E731
+            if method == "barnes_hut" and args.force_precision:
+                sim.set_force_precision(args.force_precision)
 
     def fence():
         sim.sync()
@@ -434,12 +436,16 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f32 pair forces (f64 opening-test ties, sums emptied into f64 every 16 visits), f64 state/keys" if method == "barnes_hut"
+        "dtype": ("f64 pair forces for the waves of 64 bodies whose G*rho*dt^2 > 1e-5 (library default), f32 pair forces with f64 "
+                  "sums for the others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
                  else "f32 pair forces, f64 sums/state",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": workload, "distribution": dist_name.replace("_fast", ""),
                    "bodies_per_gpu": n_total // world if strong else per_gpu, "bodies_total": n_total,
                    "theta": theta, "dt": dt, "G": G, "softening": eps, "spawn_radius": R, "method": method,
+                   # owner mode ("let") has no float64 node records yet: fp32 forces there
+                   "force_precision": None if method != "barnes_hut" else
+                                      ("f32" if (use_dist and shard_mode == "let") else (args.force_precision or "auto")),
                    "parallelism": par},
     }
 
@@ -520,6 +526,8 @@ def main():
                     help="default run only: leave out the second object (north_star's N = 10 M on this one GPU)")
     ap.add_argument("--dt", type=float, default=None,
                     help="override the workload's step (the `4k_galaxy_1m` preset steps galaxy_1m_bh at 0.05 / 5 = 0.01)")
+    ap.add_argument("--force-precision", default=None, choices=["auto", "f32", "f64"],
+                    help="pair-force arithmetic (default: the library's, auto; single-GPU Barnes-Hut workloads only)")
     ap.add_argument("--theta", type=float, default=None,
                     help="override the workload's opening angle (exploration; BASELINE's metric is theta = 0.5)")
     args = ap.parse_args()
@@ -566,7 +574,7 @@ def main():
     # fits the "few minutes" budget with its CPU baseline).  north_star's target is quoted at N = 10 M, which
     # also fits one GPU: the same measurement for the config-4 input rides along as a second object.
     plain_default = (world == 1 and not use_dist and args.workload == "galaxy_1m_bh" and not args.bodies_per_gpu
-                     and args.theta is None and args.dt is None and not args.skip_10m)
+                     and args.theta is None and args.dt is None and not args.skip_10m and not args.force_precision)
     if plain_default:
         out["north_star_10m"] = measure_nbody(args, "collision_10m_bh", 1, 0, dev, False, min(args.steps, 10),
                                               min(args.warmup, 2), cpu_budget_s=10.0)
