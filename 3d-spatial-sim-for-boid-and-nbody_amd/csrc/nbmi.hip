@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                                                       const uint32_t *__restrict__ perm, double G, TreeInfo *info) {
     __shared__ uint8_t tree[2 * kEmitTile];   // heap: tree[kEmitTile + i] = delta[base + i] + 1, inner nodes = min of children
     __shared__ uint8_t dprev;                 // delta[base - 1] + 1
-    __shared__ uint32_t cells[kCellChunk];    // (local body index << 8) | level
+    __shared__ uint32_t cells[kCellChunk];    // node slot -> (local body index << 6) | k (k-th node of that body)
     const int t = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * kEmitTile;
     const int64_t total = n + pex_at(PexL, subPex, n);
@@ -606,19 +606,39 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
     const int64_t q_tile = pex_at(PexL, subPex, base < n ? base : n);
     const int64_t tile_end = base + kEmitTile < n ? base + kEmitTile : n;
     const int64_t ncell = pex_at(PexL, subPex, tile_end) - q_tile;  // cells started inside this tile
+    const int64_t nnode = (tile_end - base) + ncell;                // the tile's nodes: one contiguous run of indices
+    const int64_t idx0 = base + q_tile;                             // ... starting here
     const double bounds = info->bounds;
     const unsigned bandk = band_half_ulps(__longlong_as_double((long long)info->maxabs_bits), eps);
-    for (int64_t c0 = 0; c0 == 0 || c0 < ncell; c0 += kCellChunk) {
-        // one thread per body: the leaf (first chunk only) and the body's cells that fall into this chunk
+    // The tile's nodes are written in INDEX order, consecutive lanes = consecutive nodes (a wave's stores of the
+    // 24 / 40 / 32-byte records then cover one contiguous stretch of each array; a thread per body / per cell wrote
+    // every record into a different cache line: 2.3 TB/s of mostly partial-line traffic at 10 M bodies).  Which
+    // (body, k) a node index belongs to comes from a table in LDS that the bodies fill, kCellChunk slots at a time:
+    // local node slot of body i's k-th node (its cnt cells, then its leaf) = i + (pex(r) - q_tile) + k.
+    for (int64_t c0 = 0; c0 < nnode; c0 += kCellChunk) {
         for (int i = t; i < kEmitTile; i += kBlock) {
             const int64_t r = base + i;
             if (r >= n) break;
             const int d = (int)tree[kEmitTile + i] - 1;
             const int dp = (int)(i > 0 ? tree[kEmitTile + i - 1] : dprev) - 1;
             const int cnt = d > dp ? d - dp : 0;
-            const int64_t q0 = pex_at(PexL, subPex, r);
-            if (c0 == 0) {
-                const int64_t idx = r + q0 + cnt;
+            const int64_t s0 = i + (pex_at(PexL, subPex, r) - q_tile) - c0;
+            for (int k = 0; k <= cnt; k++) {
+                const int64_t c = s0 + k;
+                if (c >= 0 && c < kCellChunk) cells[c] = ((uint32_t)i << 6) | (uint32_t)k;
+            }
+        }
+        __syncthreads();
+        const int64_t here = nnode - c0 < kCellChunk ? nnode - c0 : kCellChunk;
+        for (int64_t c = t; c < here; c += kBlock) {
+            const uint32_t cl = cells[c];
+            const int i = (int)(cl >> 6), k = (int)(cl & 63u);
+            const int64_t r = base + i;
+            const int64_t idx = idx0 + c0 + c;
+            const int d = (int)tree[kEmitTile + i] - 1;
+            const int dp = (int)(i > 0 ? tree[kEmitTile + i - 1] : dprev) - 1;
+            const int cnt = d > dp ? d - dp : 0;
+            if (k == cnt) {  // the body's leaf
                 const float4 p = posm_s[r];
                 Node lf;
                 lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
@@ -634,18 +654,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                     node_ref[idx] = (int32_t)r;
                     node_level[idx] = (uint8_t)((d > dp ? d : dp) + 1);
                 }
+                continue;
             }
-            for (int k = 0; k < cnt; k++) {
-                const int64_t c = q0 - q_tile + k - c0;
-                if (c >= 0 && c < kCellChunk) cells[c] = ((uint32_t)i << 8) | (uint32_t)(dp + 1 + k);
-            }
-        }
-        __syncthreads();
-        const int64_t here = ncell - c0 < kCellChunk ? ncell - c0 : kCellChunk;
-        for (int64_t c = t; c < here; c += kBlock) {
-            const uint32_t cl = cells[c];
-            const int i = (int)(cl >> 8), lev = (int)(cl & 255u);
-            const int64_t r = base + i;
+            const int lev = dp + 1 + k;
             // first local index j >= i with delta[j] + 1 <= lev
             unsigned h = (unsigned)(kEmitTile + i);
             bool found = false;
@@ -692,7 +703,6 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             double cx = 0.0, cy = 0.0, cz = 0.0;
             if (M > 0.0) { cx = mx / M; cy = my / M; cz = mz / M; }
             const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
-            const int64_t idx = r + q_tile + c0 + c;
             Node nd;
             nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz;
             nd.gm = (float)M;  // the moments are sums of G*m
@@ -888,7 +898,7 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
 // next_off), which takes those instructions' issue time out of the per-wave dependent chain.  The whole loop
 // is one asm statement (4 visits per trip, banks A B A B) so that no compiler-generated code runs while a load
 // is in flight; a self-looping sentinel node after the last one makes overshooting harmless.
-#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI, LOPEN, LJOIN) \
+#define NBMI_VISIT_X(OFF, RES, ACC, WAIT, CX, CY, CZ, GM, S2T, NXT, NEXTLO, NEXTHI, LOPEN, LJOIN, LSKIP) \
     "v_cmpx_ge_u32_e64 s[44:45], " OFF ", " RES "\n"           \
     WAIT                                                       \
     "v_sub_f32_e32 %[dx], " CX ", %[px]\n"                     \
@@ -912,12 +922,13 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "v_fmac_f32_e32 %[ax" ACC "], %[dx], %[f]\n"               \
     "v_fmac_f32_e32 %[ay" ACC "], %[dy], %[f]\n"               \
     "v_fmac_f32_e32 %[az" ACC "], %[dz], %[f]\n"               \
-    "s_mov_b64 exec, -1\n"
+    "s_mov_b64 exec, -1\n"                                    \
+    LSKIP ":\n"
 // the out-of-line half of a visit that some lane opens (s[56:57] = openers, s[46:47] = takers; 20 % of the visits):
 // only an opener can lie inside the uncertainty band, so the near-tie check lives here - one v_cmp of the openers
 // against the lower band edge; a hit leaves the loop BEFORE the visit has changed anything, otherwise the cursor
 // moves to the next node in memory and the visit goes on
-#define NBMI_OPEN_X(OFF, S2T, LOPEN, LJOIN, EXITL)   \
+#define NBMI_OPEN_X(OFF, S2T, NEXTLO, NEXTHI, LOPEN, LJOIN, LSKIP, EXITL)   \
     LOPEN ":\n"                                      \
     "s_sub_u32 s54, " S2T ", %[band2]\n"             \
     "s_mov_b64 exec, s[56:57]\n"                     \
@@ -926,24 +937,31 @@ __device__ __forceinline__ unsigned visit(const Node *__restrict__ nodes, unsign
     "s_cmp_lg_u64 s[42:43], 0\n"                     \
     "s_cbranch_scc1 " EXITL "\n"                     \
     "s_add_u32 " OFF ", " OFF ", 24\n"               \
-    "s_branch " LJOIN "b\n"
+    "s_cmp_lg_u64 s[46:47], 0\n"                     \
+    "s_cbranch_scc1 " LJOIN "b\n"                    \
+    /* [r3] nobody takes the node (every lane that takes part opens it): request the next record and skip the */ \
+    /* eight force instructions */                   \
+    "s_load_dwordx4 " NEXTLO ", %[base], " OFF "\n"  \
+    "s_load_dwordx2 " NEXTHI ", %[base], " OFF " offset:16\n" \
+    "s_mov_b64 exec, -1\n"                           \
+    "s_branch " LSKIP "b\n"
 #define NBMI_WAIT "s_waitcnt lgkmcnt(0)\n"
-#define NBMI_VISIT_A(LO, LJ) \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]", LO, LJ)
-#define NBMI_VISIT_B(LO, LJ) \
-    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]", LO, LJ)
-#define NBMI_OPEN_A(LO, LJ) NBMI_OPEN_X("%[off]", "s40", LO, LJ, "7f")
-#define NBMI_OPEN_B(LO, LJ) NBMI_OPEN_X("%[off]", "s52", LO, LJ, "7f")
+#define NBMI_VISIT_A(LO, LJ, LS) \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s36", "s37", "s38", "s39", "s40", "s41", "s[48:51]", "s[52:53]", LO, LJ, LS)
+#define NBMI_VISIT_B(LO, LJ, LS) \
+    NBMI_VISIT_X("%[off]", "%[resume]", "", NBMI_WAIT, "s48", "s49", "s50", "s51", "s52", "s53", "s[36:39]", "s[40:41]", LO, LJ, LS)
+#define NBMI_OPEN_A(LO, LJ, LS) NBMI_OPEN_X("%[off]", "s40", "s[48:51]", "s[52:53]", LO, LJ, LS, "7f")
+#define NBMI_OPEN_B(LO, LJ, LS) NBMI_OPEN_X("%[off]", "s52", "s[36:39]", "s[40:41]", LO, LJ, LS, "7f")
 // two cursors in one wave (walk_pair_asm): cursor 1 uses banks s[36:41] / s[48:53], cursor 2 uses
 // s[60:65] / s[68:73]; the trip waits ONCE for both cursors' records
 #define NBMI_VISIT_1A NBMI_VISIT_A
 #define NBMI_VISIT_1B NBMI_VISIT_B
-#define NBMI_VISIT_2A(LO, LJ) \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]", LO, LJ)
-#define NBMI_VISIT_2B(LO, LJ) \
-    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", LO, LJ)
-#define NBMI_OPEN_2A(LO, LJ) NBMI_OPEN_X("%[off2]", "s64", LO, LJ, "8f")
-#define NBMI_OPEN_2B(LO, LJ) NBMI_OPEN_X("%[off2]", "s72", LO, LJ, "8f")
+#define NBMI_VISIT_2A(LO, LJ, LS) \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s60", "s61", "s62", "s63", "s64", "s65", "s[68:71]", "s[72:73]", LO, LJ, LS)
+#define NBMI_VISIT_2B(LO, LJ, LS) \
+    NBMI_VISIT_X("%[off2]", "%[resume2]", "2", "", "s68", "s69", "s70", "s71", "s72", "s73", "s[60:63]", "s[64:65]", LO, LJ, LS)
+#define NBMI_OPEN_2A(LO, LJ, LS) NBMI_OPEN_X("%[off2]", "s64", "s[68:71]", "s[72:73]", LO, LJ, LS, "8f")
+#define NBMI_OPEN_2B(LO, LJ, LS) NBMI_OPEN_X("%[off2]", "s72", "s[60:63]", "s[64:65]", LO, LJ, LS, "8f")
 // Two-level sums: the loops add into fp32 accumulators (one instruction per component and visit); every few
 // trips those are emptied into float64 sums (NBMI_FLUSH: convert, add, clear), so an fp32 running sum never grows
 // beyond a dozen terms.  Measured at 1 M bodies against the float64 oracle, per-body relative acceleration error:
@@ -994,10 +1012,10 @@ __device__ __forceinline__ void walk4_asm(const Node *nodes, unsigned &off, unsi
     asm volatile("s_mov_b32 %[cnt], 3\n"
                  "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A("21", "31") NBMI_VISIT_B("22", "32") NBMI_VISIT_A("23", "33") NBMI_VISIT_B("24", "34") NBMI_TRIP_COUNT
+                 "1:\n" NBMI_VISIT_A("21", "31", "51") NBMI_VISIT_B("22", "32", "52") NBMI_VISIT_A("23", "33", "53") NBMI_VISIT_B("24", "34", "54") NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc1 1b\n"
-                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_B("22", "32") NBMI_OPEN_A("23", "33") NBMI_OPEN_B("24", "34"),
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31", "51") NBMI_OPEN_B("22", "32", "52") NBMI_OPEN_A("23", "33", "53") NBMI_OPEN_B("24", "34", "54"),
                             NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "3")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
                    [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
@@ -1018,12 +1036,12 @@ __device__ __forceinline__ void walk1_asm(const Node *nodes, unsigned &off, unsi
     asm volatile("s_mov_b32 %[cnt], 7\n"
                  "s_load_dwordx4 s[36:39], %[base], %[off]\n"
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
-                 "1:\n" NBMI_VISIT_A("21", "31")
+                 "1:\n" NBMI_VISIT_A("21", "31", "51")
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B("22", "32") NBMI_TRIP_COUNT
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_B("22", "32", "52") NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc1 1b\n"
-                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_B("22", "32"), NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "7")
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31", "51") NBMI_OPEN_B("22", "32", "52"), NBMI_FLUSH("%[ax]", "%[ay]", "%[az]"), "7")
                  : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [ax] "+v"(ax), [ay] "+v"(ay),
                    [az] "+v"(az), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz), [t64] "=&v"(t64), [cnt] "=&s"(cnt),
                    [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [inv] "=&v"(inv),
@@ -1053,14 +1071,14 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
                  "s_load_dwordx2 s[40:41], %[base], %[off] offset:16\n"
                  "s_load_dwordx4 s[60:63], %[base], %[off2]\n"
                  "s_load_dwordx2 s[64:65], %[base], %[off2] offset:16\n"
-                 "1:\n" NBMI_VISIT_1A("21", "31") NBMI_VISIT_2A("22", "32")
+                 "1:\n" NBMI_VISIT_1A("21", "31", "51") NBMI_VISIT_2A("22", "32", "52")
                  "s_cmp_lt_u32 %[off], %[end]\n"
-                 "s_cbranch_scc0 9f\n" NBMI_VISIT_1B("23", "33") NBMI_VISIT_2B("24", "34")
+                 "s_cbranch_scc0 9f\n" NBMI_VISIT_1B("23", "33", "53") NBMI_VISIT_2B("24", "34", "54")
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc0 9f\n" NBMI_TRIP_COUNT
                  "s_cmp_lt_u32 %[off2], %[end2]\n"
                  "s_cbranch_scc1 1b\n"
-                 NBMI_EXITS(NBMI_OPEN_A("21", "31") NBMI_OPEN_2A("22", "32") NBMI_OPEN_B("23", "33") NBMI_OPEN_2B("24", "34"),
+                 NBMI_EXITS(NBMI_OPEN_A("21", "31", "51") NBMI_OPEN_2A("22", "32", "52") NBMI_OPEN_B("23", "33", "53") NBMI_OPEN_2B("24", "34", "54"),
                             NBMI_FLUSH("%[ax]", "%[ay]", "%[az]") NBMI_FLUSH("%[ax2]", "%[ay2]", "%[az2]"), "3")
                  : [off] "+s"(off1), [off2] "+s"(off2), [which] "+s"(which), [resume] "+v"(resume1),
                    [resume2] "+v"(resume2), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ax2] "+v"(ax2),
@@ -1087,7 +1105,7 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
 //   G m d2^(-3/2) = G m y0^3 (1 + 1.5 e) [+ O(e^2) = 1e-14];  three float64 FMAs into the sums.
 // 17 float64-rate + 4 fp32-rate vector instructions per visit (the fp32 visit: 16 fp32-rate).
 // ---------------------------------------------------------------------------------------
-#define NBMI_V64_X(CX, CY, CZ, GM, S2T, NXT, NEXT8, NEXT2, LOPEN, LJOIN) \
+#define NBMI_V64_X(CX, CY, CZ, GM, S2T, NXT, NEXT8, NEXT2, LOPEN, LJOIN, LSKIP) \
     "v_cmpx_ge_u32_e64 s[58:59], %[off], %[resume]\n"          \
     "s_waitcnt lgkmcnt(0)\n"                                   \
     "v_add_f64 %[dx], " CX ", -%[px]\n"                        \
@@ -1116,8 +1134,9 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
     "v_fma_f64 %[sx], %[dx], %[w], %[sx]\n"                    \
     "v_fma_f64 %[sy], %[dy], %[w], %[sy]\n"                    \
     "v_fma_f64 %[sz], %[dz], %[w], %[sz]\n"                    \
-    "s_mov_b64 exec, -1\n"
-#define NBMI_O64_X(S2T, LOPEN, LJOIN)                \
+    "s_mov_b64 exec, -1\n"                                    \
+    LSKIP ":\n"
+#define NBMI_O64_X(S2T, NEXT8, NEXT2, LOPEN, LJOIN, LSKIP) \
     LOPEN ":\n"                                      \
     "s_sub_u32 s66, " S2T ", %[band2]\n"             \
     "s_mov_b64 exec, s[62:63]\n"                     \
@@ -1126,11 +1145,19 @@ __device__ __forceinline__ void walk_pair_asm(const Node *nodes, unsigned &off1,
     "s_cmp_lg_u64 s[64:65], 0\n"                     \
     "s_cbranch_scc1 7f\n"                            \
     "s_add_u32 %[off], %[off], 40\n"                 \
-    "s_branch " LJOIN "b\n"
-#define NBMI_V64_A(LO, LJ) \
-    NBMI_V64_X("s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s44", "s45", "s[48:55]", "s[56:57]", LO, LJ)
-#define NBMI_V64_B(LO, LJ) \
-    NBMI_V64_X("s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s56", "s57", "s[36:43]", "s[44:45]", LO, LJ)
+    "s_cmp_lg_u64 s[60:61], 0\n"                     \
+    "s_cbranch_scc1 " LJOIN "b\n"                    \
+    /* nobody takes the node: request the next record, skip the force block */ \
+    "s_load_dwordx8 " NEXT8 ", %[base], %[off]\n"    \
+    "s_load_dwordx2 " NEXT2 ", %[base], %[off] offset:32\n" \
+    "s_mov_b64 exec, -1\n"                           \
+    "s_branch " LSKIP "b\n"
+#define NBMI_V64_A(LO, LJ, LS) \
+    NBMI_V64_X("s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s44", "s45", "s[48:55]", "s[56:57]", LO, LJ, LS)
+#define NBMI_V64_B(LO, LJ, LS) \
+    NBMI_V64_X("s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s56", "s57", "s[36:43]", "s[44:45]", LO, LJ, LS)
+#define NBMI_O64_A(LO, LJ, LS) NBMI_O64_X("s44", "s[48:55]", "s[56:57]", LO, LJ, LS)
+#define NBMI_O64_B(LO, LJ, LS) NBMI_O64_X("s56", "s[36:43]", "s[44:45]", LO, LJ, LS)
 
 // walks from `off` to the end of the NodeD array (4 visits per loop test, the sentinel absorbs the overshoot) or
 // until a near-tie stops it (which = 1, cursor on the tied node)
@@ -1142,11 +1169,11 @@ __device__ __forceinline__ void walk4_asm64(const NodeD *nodesd, unsigned &off, 
     const double c15 = 1.5;
     asm volatile("s_load_dwordx8 s[36:43], %[base], %[off]\n"
                  "s_load_dwordx2 s[44:45], %[base], %[off] offset:32\n"
-                 "1:\n" NBMI_V64_A("21", "31") NBMI_V64_B("22", "32") NBMI_V64_A("23", "33") NBMI_V64_B("24", "34")
+                 "1:\n" NBMI_V64_A("21", "31", "51") NBMI_V64_B("22", "32", "52") NBMI_V64_A("23", "33", "53") NBMI_V64_B("24", "34", "54")
                  "s_cmp_lt_u32 %[off], %[end]\n"
                  "s_cbranch_scc1 1b\n"
                  "s_branch 9f\n"
-                 NBMI_O64_X("s44", "21", "31") NBMI_O64_X("s56", "22", "32") NBMI_O64_X("s44", "23", "33") NBMI_O64_X("s56", "24", "34")
+                 NBMI_O64_A("21", "31", "51") NBMI_O64_B("22", "32", "52") NBMI_O64_A("23", "33", "53") NBMI_O64_B("24", "34", "54")
                  "7:\n"
                  "s_mov_b64 exec, -1\n"
                  "s_mov_b32 %[which], 1\n"
@@ -1652,6 +1679,8 @@ __global__ __launch_bounds__(kBlock) void k_walk_lane(const Node *__restrict__ n
 //   10 ... 14  as 2 with ONE quantity rounded to fp32: the coordinate differences / dist_sq / the reciprocal square
 //      root (v_rsq_f32) / [13: v_rsq_f32 seed + one Newton step in float64 - the candidate product form] / each
 //      contribution before it is added
+//   15 fp32 with the systematic errors removed (exact-residual Newton step on v_rsq_f32, G m as two floats), float64
+//      accumulation;  16 the same on exact coordinate differences rounded to fp32;  17 = 16 with two-level fp32 sums
 //   20 float64 (as 13) for the bodies inside the cylindrical radius NBMI_PREC_NEAR (length units), 1 for the others
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ nodes, const double4 *__restrict__ diag64,
@@ -1678,6 +1707,7 @@ __global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ n
     unsigned resume = valid ? 0u : 0xffffffffu;
     double sx = 0.0, sy = 0.0, sz = 0.0;
     float fx = 0.f, fy = 0.f, fz = 0.f;
+    int nflush = 0;
     const int mode = P.prec;
     const double eps2d = tab->eps2;
     unsigned off = 0u;
@@ -1725,16 +1755,34 @@ __global__ __launch_bounds__(kBlock) void k_walk_diag(const Node *__restrict__ n
                     const double4 c = diag64[off / kNodeBytes];
                     const float clx = (float)(c.x - (double)nd.cx), cly = (float)(c.y - (double)nd.cy), clz = (float)(c.z - (double)nd.cz);
                     ex = dx + (clx - plx); ey = dy + (cly - ply); ez = dz + (clz - plz);
-                } else if (mode == 6 || mode == 8) {
+                } else if (mode == 6 || mode == 8 || mode == 16 || mode == 17) {
                     const double4 c = diag64[off / kNodeBytes];
                     ex = (float)(c.x - qx); ey = (float)(c.y - qy); ez = (float)(c.z - qz);
                 }
-                const float d2 = (mode == 5 || mode == 6 || mode == 8) ? fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, P.eps2))) : dist_sq;
+                const float d2 = (mode == 5 || mode == 6 || mode == 8 || mode == 16 || mode == 17) ? fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, P.eps2))) : dist_sq;
                 float inv = __builtin_amdgcn_rsqf(d2);
                 if (mode == 8) inv = inv * fmaf(-0.5f * d2 * inv, inv, 1.5f);
-                const float f = (nd.gm * inv) * (inv * inv);
-                if (mode == 7) {
+                float f;
+                if (mode >= 15 && mode <= 17) {
+                    // "enhanced fp32": the SYSTEMATIC errors removed (one Newton step with the exact residual, G m as two
+                    // floats), the random roundings of fp32 kept
+                    const float t = d2 * inv, tl = fmaf(d2, inv, -t);
+                    float e = fmaf(-t, inv, 1.0f);
+                    e = fmaf(-tl, inv, e);
+                    inv = fmaf(0.5f * inv, e, inv);
+                    const double4 c = diag64[off / kNodeBytes];
+                    const float gml = (float)(c.w - (double)nd.gm);
+                    const float g3 = (inv * inv) * inv;
+                    f = fmaf(gml, g3, nd.gm * g3);
+                } else {
+                    f = (nd.gm * inv) * (inv * inv);
+                }
+                if (mode == 7 || mode == 17) {
                     fx = fmaf(ex, f, fx); fy = fmaf(ey, f, fy); fz = fmaf(ez, f, fz);
+                    if (mode == 17 && (++nflush & 15) == 0) {  // two-level sums like the product loop
+                        sx += (double)fx; sy += (double)fy; sz += (double)fz;
+                        fx = fy = fz = 0.f;
+                    }
                 } else {
                     sx += (double)(ex * f); sy += (double)(ey * f); sz += (double)(ez * f);
                 }
