@@ -2353,11 +2353,13 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
                                                      int64_t num_nodes, const double *__restrict__ boxes,
                                                      const double *__restrict__ supers, const double *__restrict__ megas,
                                                      const double *__restrict__ rankbox, int world, int me, double theta, double eps2,
-                                                     int32_t *__restrict__ diff, int64_t stride) {
+                                                     int32_t *__restrict__ diff, int64_t stride, const TreeInfo *__restrict__ info) {
     // (a wave-uniform form of these loops - a level entered if ANY lane needs it, box data by scalar loads -
     // was slower, 266 vs 190 us at 8 ranks: the lanes' early exits are worth more than the cheaper loads)
+    // `num_nodes` is the host's launch bound (it may be an estimate from the previous step); the tree's own count is
+    // on the device
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_nodes) return;
+    if (i >= num_nodes || i >= info->num_nodes) return;
     const Node nd = nodes[i];
     if (__float_as_int(nd.s2t) == 0) return;  // a leaf: nothing below it
     const Node64 c = n64[i];
@@ -2386,10 +2388,11 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
     }
 }
 __global__ __launch_bounds__(kBlock) void k_let_keep(const int32_t *__restrict__ diff, const int32_t *__restrict__ diff_ex,
-                                                     int64_t num_nodes, int64_t stride, int32_t *__restrict__ keep) {
+                                                     int64_t num_nodes, int64_t stride, int32_t *__restrict__ keep,
+                                                     const TreeInfo *__restrict__ info) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t o = (int64_t)blockIdx.y * stride;
-    if (i < num_nodes) keep[o + i] = (diff_ex[o + i] + diff[o + i]) == 0 ? 1 : 0;
+    if (i < num_nodes) keep[o + i] = (i < info->num_nodes && (diff_ex[o + i] + diff[o + i]) == 0) ? 1 : 0;
 }
 // kept nodes move to their new index in the destination's segment; links are re-based to the compacted
 // numbering (a kept node's successor is always kept: it hangs off one of the node's own ancestors).  A row of
@@ -2398,10 +2401,11 @@ constexpr int kLetRow = 56;
 __global__ __launch_bounds__(kBlock) void k_let_compact(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
                                                         const int32_t *__restrict__ keep, const int32_t *__restrict__ newidx,
                                                         int64_t num_nodes, int64_t stride, int64_t capacity, int me,
-                                                        const int64_t *__restrict__ seg_off, char *__restrict__ out) {
+                                                        const int64_t *__restrict__ seg_off, char *__restrict__ out,
+                                                        const TreeInfo *__restrict__ info) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int j = blockIdx.y;
-    if (j == me || i >= num_nodes) return;
+    if (j == me || i >= num_nodes || i >= info->num_nodes) return;
     const int64_t o = (int64_t)j * stride;
     if (!keep[o + i]) return;
     const int64_t k = seg_off[j] + newidx[o + i];
@@ -2461,7 +2465,12 @@ __global__ __launch_bounds__(kBlock) void k_let_append(const char *__restrict__ 
     const double *d = reinterpret_cast<const double *>(row + kNodeBytes);
     n64[base + k] = Node64{d[0], d[1], d[2], d[3]};
 }
+// total < 0: nothing was received, the walk array is the own tree as built (its sentinel is in place)
 __global__ void k_let_finish(Node *__restrict__ nodes, int64_t total, TreeInfo *info) {
+    if (total < 0) {
+        info->walk_nodes = info->num_nodes;
+        return;
+    }
     Node sn;
     sn.cx = sn.cy = sn.cz = 1.0e30f;
     sn.gm = 0.f; sn.s2t = 0.f;
@@ -2542,6 +2551,9 @@ struct nbmi_sim {
     int32_t *let_diff = nullptr, *let_scan = nullptr, *let_keep = nullptr, *let_tiles = nullptr, *let_ranges = nullptr;
     double *let_supers = nullptr, *let_megas = nullptr, *let_rankbox = nullptr;
     int64_t let_stride = 0, let_tile_stride = 0;  // rows between two destinations' work arrays
+    TreeInfo *h_info = nullptr;   // pinned host copy of the tree header, refreshed by every nbmi_owner_adopt
+    hipEvent_t ev_info = nullptr;  // ... complete when this event is
+    int64_t last_nodes = -1;      // num_nodes of the previous step's own tree (launch bound of this step's tree export)
     // frame codec: previous decoded frame (positions then colours, float32, caller's order) and the int16 payload
     float *frame_prev = nullptr;
     int16_t *frame_q = nullptr;
@@ -2882,6 +2894,8 @@ void nbmi_destroy(nbmi_sim *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
+    if (s->ev_info) (void)hipEventDestroy(s->ev_info);
+    if (s->h_info) (void)hipHostFree(s->h_info);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -3457,6 +3471,11 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
             dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) ||
             dev_alloc(s, &s->let_megas, (size_t)6 * kMegasPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
             rc = -2;
+        if (rc == 0 && (hipHostMalloc((void **)&s->h_info, sizeof(TreeInfo)) != hipSuccess || hipEventCreate(&s->ev_info) != hipSuccess ||
+                        hipMemsetAsync(s->let_dead, 0, (size_t)c, s->stream) != hipSuccess)) {
+            nbmi::set_error("nbmi_create_owner: host buffer / event allocation failed");
+            rc = -2;
+        }
     }
     if (rc == 0 && n > 0) {  // global ids instead of the row numbers k_split_state wrote
         hipError_t e = hipMemcpyAsync(s->stage, ids, (size_t)n * 4, hipMemcpyHostToDevice, s->stream);
@@ -3493,7 +3512,7 @@ int nbmi_owner_maxabs(nbmi_sim *s, void *dev_maxabs) {
     if (int rc = enqueue_maxabs(s)) return rc;  // also clears the per-step tree header
     // a non-negative double and its bit pattern order the same way: the word IS the double
     NBMI_HIP_CHECK(hipMemcpyAsync(dev_maxabs, &s->info->maxabs_bits, 8, hipMemcpyDeviceToDevice, s->stream));
-    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));  // (stream-ordered callers: nbmi_set_exchange_sync(0))
     return 0;
 }
 
@@ -3505,12 +3524,13 @@ int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, in
     }
     hipStream_t st = s->stream;
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
+    if (s->world == 1) return 0;  // one owner: no splitters to find (nbmi_owner_adopt computes the keys it sorts by)
     Bodies cur = s->buf[s->curbuf];
     if (s->n > 0 && s->hilbert) k_keys<true><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
     else if (s->n > 0) k_keys<false><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
     k_key_samples<<<(nsamples + kBlock - 1) / kBlock, kBlock, 0, st>>>(s->key_hi, s->n, nsamples, (uint64_t *)dev_samples);
     NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -3525,6 +3545,10 @@ int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_sam
     const int64_t n = s->n, stride = s->let_stride;
     const int W = s->world;
     for (int j = 0; j < W; j++) counts[j] = 0;
+    if (W == 1) {  // nobody to hand bodies to (the dead flags stay clear)
+        s->n_leaving = 0;
+        return 0;
+    }
     k_splitters<<<(total_samples + kBlock - 1) / kBlock, kBlock, 0, st>>>((const uint64_t *)dev_all_samples, total_samples, W, s->let_split);
     if (n > 0) {
         // only the bodies whose key has left this rank's range travel; everybody else stays where it is
@@ -3565,7 +3589,11 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
     // the tree header of this step: cleared, then the GLOBAL extent (every rank builds inside the same root cube)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
-    if (n_new > 0) {
+    if (n_new > 0 && s->world == 1) {
+        // one owner: the plain build (no dead rows, no boxes to publish)
+        if (int rc = enqueue_local_sort(s, -1)) return rc;
+        if (int rc = enqueue_global_tree(s, false)) return rc;
+    } else if (n_new > 0) {
         // rank of every dead row among the dead rows (exclusive scan of the flags): their place behind the live ones
         k_dead_flags<<<nblocks(n_work), kBlock, 0, st>>>(s->let_dead, n_work, s->let_keep);
         if (int rc = enqueue_iscan(s, s->let_keep, n_work, s->let_scan)) return rc;
@@ -3588,8 +3616,11 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
         NBMI_HIP_CHECK(hipStreamSynchronize(st));  // `empty` dies here
     }
     NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipStreamSynchronize(st));
-    s->tree_valid = n_new > 0;
+    // the tree header travels to the host behind the build; nbmi_owner_export_let / _step read it after their own wait
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->h_info, s->info, sizeof(TreeInfo), hipMemcpyDeviceToHost, st));
+    NBMI_HIP_CHECK(hipEventRecord(s->ev_info, st));
+    if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    s->tree_valid = n_new > 0 && s->world > 1;
     return 0;
 }
 
@@ -3599,26 +3630,44 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int
     for (int j = 0; j < s->world; j++) counts[j] = 0;
     if (s->n == 0 || s->world == 1) return 0;
     hipStream_t st = s->stream;
-    TreeInfo h;
-    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
-    NBMI_HIP_CHECK(hipStreamSynchronize(st));
-    if (h.error) return check_device_error(s);
-    const int64_t nn = h.num_nodes, stride = s->let_stride;
+    const int64_t stride = s->let_stride;
     const int W = s->world;
-    NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)stride * W * 4, st));
-    k_super_boxes<<<(W * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, W * kSupersPerRank, s->let_supers);
-    k_rank_boxes<<<1, kMaxWorld * kMegasPerRank, 0, st>>>(s->let_supers, W, s->let_megas, s->let_rankbox);
-    k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_megas, s->let_rankbox, W,
-                                              s->rank, s->theta, s->softening * s->softening, s->let_diff, stride);
-    if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
-    k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep);
-    if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan, W, stride)) return rc;
-    k_let_counts<<<1, 64, 0, st>>>(s->let_scan, nn, stride, W, s->rank, s->let_counts);
-    k_let_compact<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, stride,
-                                                                            s->let_capacity, s->rank, s->let_counts + W, (char *)dev_let);
-    NBMI_HIP_CHECK(hipGetLastError());
-    NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
-    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    // How many nodes the own tree has is known on the device; the host needs a launch bound.  The previous step's
+    // count + 2 % is one (a tree changes by a few nodes in a thousand per step): no wait for this step's header
+    // before the kernels are enqueued, ONE wait at the end for the counts - and the header, which says whether the
+    // bound held (if not: once more with the exact count).
+    int64_t nn = -1;
+    if (s->last_nodes > 0 && !s->exchange_sync) {
+        nn = s->last_nodes + s->last_nodes / 50 + 4096;
+        if (nn > s->own_node_rows) nn = s->own_node_rows;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (nn < 0) {
+            NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));
+            if (s->h_info->error) return check_device_error(s);
+            nn = s->h_info->num_nodes;
+        }
+        NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)stride * W * 4, st));
+        k_super_boxes<<<(W * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, W * kSupersPerRank, s->let_supers);
+        k_rank_boxes<<<1, kMaxWorld * kMegasPerRank, 0, st>>>(s->let_supers, W, s->let_megas, s->let_rankbox);
+        k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_megas,
+                                                  s->let_rankbox, W, s->rank, s->theta, s->softening * s->softening, s->let_diff, stride,
+                                                  s->info);
+        if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
+        k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep, s->info);
+        if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan, W, stride)) return rc;
+        k_let_counts<<<1, 64, 0, st>>>(s->let_scan, nn, stride, W, s->rank, s->let_counts);
+        k_let_compact<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, stride,
+                                                                                s->let_capacity, s->rank, s->let_counts + W, (char *)dev_let,
+                                                                                s->info);
+        NBMI_HIP_CHECK(hipGetLastError());
+        NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
+        NBMI_HIP_CHECK(hipStreamSynchronize(st));  // the one wait: counts + (long since) this step's header
+        if (s->h_info->error) return check_device_error(s);
+        if (s->h_info->num_nodes <= nn) break;
+        nn = s->h_info->num_nodes;  // the estimate was too small: the exact count now
+    }
+    s->last_nodes = s->h_info->num_nodes;
     int64_t total = 0;
     for (int j = 0; j < W; j++) total += counts[j];
     if (total > s->let_capacity) {
@@ -3634,9 +3683,17 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, do
     if (!counts || (s->world > 1 && !dev_recv)) { nbmi::set_error("nbmi_owner_step: null buffer"); return NBMI_ERR_ARG; }
     if (s->n == 0) return 0;
     hipStream_t st = s->stream;
-    TreeInfo h;
-    NBMI_HIP_CHECK(hipMemcpyAsync(&h, s->info, sizeof(h), hipMemcpyDeviceToHost, st));
-    NBMI_HIP_CHECK(hipStreamSynchronize(st));
+    if (s->world == 1) {  // nothing received: the walk array is the own tree; an overflow freezes the walk and is reported at the next sync
+        k_let_finish<<<1, 1, 0, st>>>(s->nodes, -1, s->info);
+        NBMI_HIP_CHECK(hipGetLastError());
+        if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
+        s->curbuf ^= 1;
+        s->tree_valid = false;
+        s->maxabs_fused = s->fuse_maxabs;  // the walk left max |coordinate| of what it wrote
+        return 0;
+    }
+    NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));  // (long complete: nbmi_owner_export_let waited behind it)
+    const TreeInfo &h = *s->h_info;
     if (h.error) return check_device_error(s);
     int64_t total = h.num_nodes, seen = 0;
     for (int j = 0; j < s->world; j++) {  // the received trees are packed one after the other, in rank order
@@ -3656,6 +3713,7 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, do
     if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
     s->curbuf ^= 1;
     s->tree_valid = false;
+    s->maxabs_fused = s->fuse_maxabs;  // the walk left max |coordinate| of the rows it wrote (all of this rank's live bodies)
     return 0;
 }
 

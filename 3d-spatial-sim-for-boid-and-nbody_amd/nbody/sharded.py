@@ -215,6 +215,14 @@ class HipLetEngine:
         self.let_send = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
         self.let_recv = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)  # the fills ran on torch's stream, the library has its own
+        # [r3] Collectives are enqueued on the LIBRARY's stream (torch sees it as an external stream): kernels, packs,
+        # collectives and unpacks order themselves, and the only host waits of a step are the two that bring the
+        # variable exchange sizes to the host (migration counts, tree counts).  NBMI_EXCHANGE_SYNC=1: the round-2
+        # behaviour (a host synchronisation after every phase and collective).
+        self.stream = None
+        if os.environ.get("NBMI_EXCHANGE_SYNC", "0") != "1":
+            self.stream = torch.cuda.ExternalStream(self.sim.stream_handle(), device=self.device)
+            self.sim.set_exchange_sync(False)
         self.wire_bytes = 0  # bytes this rank sent in the last step (rows + tree + small collectives)
         self.migrated = 0    # bodies this rank handed to other ranks in the last step
         self.let_counts = np.zeros(world, dtype=np.int64)
@@ -240,8 +248,15 @@ class HipLetEngine:
         self.sim.owner_step(self.let_recv.data_ptr(), recv_counts, dt)
 
     def wait(self):
-        """A collective issued on torch's stream has finished (the library works on its own stream)."""
-        self.torch.cuda.current_stream(self.device).synchronize()
+        """A collective issued on torch's stream has finished (only needed while the library works on a stream of its
+        own; with the shared stream the order is the stream's)."""
+        if self.stream is None:
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def stream_scope(self):
+        """Context in which torch's current stream is the library's."""
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def owned_state(self):
         """(global ids, positions f64, velocities f64) of the owned bodies."""
@@ -263,6 +278,11 @@ class LetBarnesHut:
             raise ValueError("LetBarnesHut over more than one rank needs a communicator")
 
     def step(self, dt, substeps=1):
+        scope = self.engine.stream_scope() if hasattr(self.engine, "stream_scope") else __import__("contextlib").nullcontext()
+        with scope:
+            self._step(dt, substeps)
+
+    def _step(self, dt, substeps):
         e, W = self.engine, self.world
         for _ in range(substeps):
             wire = 0

@@ -24,7 +24,7 @@ cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, os, collections, json
 out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_'+os.environ.get('TAG','x')
-KEYS=('k_walk<true','k_walk<false','k_emit_cells','k_emit_leaves','k_gather','k_keys','k_maxabs','k_direct','k_flock<true','k_reorder','k_table','k_assign')
+KEYS=('k_walk<true','k_walk<false','k_emit_tile','k_gather_scan','k_scan_subtiles','k_keys','k_tiefix','k_radix_pass','k_radix_hist','k_maxabs','k_direct','k_flock<true','k_reorder','k_table','k_assign')
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 dur=collections.defaultdict(list)
 for f in glob.glob(out+'/pass*/*/*counter_collection.csv'):
@@ -57,5 +57,5 @@ res['_csrc_sha']=h.hexdigest()[:16]   # bench.py only quotes this summary for th
 json.dump(res, open(out+'/summary.json','w'), indent=1, sort_keys=True)
 for k,d in res.items():
     if not isinstance(d, dict): continue
-    print(k, {c: (round(v,1) if isinstance(v,float) else v) for c,v in d.items() if c in ('FETCH_SIZE','WRITE_SIZE','hbm_bytes_raw','hbm_bytes_fetch_x2','_avg_us_under_pmc','TCC_HIT_sum','TCC_MISS_sum','SQ_INSTS_VALU','SQ_INSTS_SALU','SQ_WAVES')})
+    print(k, {c: (round(v,1) if isinstance(v,float) else v) for c,v in d.items() if c in ('FETCH_SIZE','WRITE_SIZE','hbm_bytes_raw','hbm_bytes_fetch_x2','_avg_us_under_pmc','TCC_HIT_sum','TCC_MISS_sum','SQ_INSTS_VALU','SQ_INSTS_SALU','SQ_WAVES','SQ_WAIT_ANY','SQ_WAVE_CYCLES','SQ_WAIT_INST_ANY','SQ_ACTIVE_INST_ANY','SQ_WAIT_INST_LDS','SQ_BUSY_CYCLES')})
 PY

@@ -129,6 +129,10 @@ class _ThreadComm:
 
         class Bound:
             def _swap(self, mine):
+                # a real collective reads `mine` in the order of the stream it is enqueued on (the library's, since
+                # round 3); these threads read each other's buffers directly, so the producer's stream is drained first
+                import torch
+                torch.cuda.current_stream().synchronize()
                 comm.slots[rank] = mine
                 comm.bar.wait()
                 got = list(comm.slots)
@@ -418,3 +422,43 @@ def test_interrupt_delivered_when_the_step_call_returns(gpu, tmp_path, monkeypat
         a, _ = rec.load_frame(cut, k)
         b, _ = rec.load_frame(whole, k)
         assert np.abs(a - b).max() <= (4e-3 if zstd else 1e-5), k
+
+
+def test_owner_mode_1m_bodies_eight_ranks_vs_single_handle_and_oracle(gpu, oracle):
+    """Owner mode at bench scale: BASELINE config 2's 1 M bodies over EIGHT ranks (threads on one
+    GPU through LetBarnesHut.step itself, collectives on the library's stream), 5 steps: within 1e-6 of the largest
+    coordinate of the single fp32 handle AND of the float64 oracle."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    from tools.presets import generate_distribution
+    np.random.seed(42)
+    n, world, steps, dt = 1_000_000, 8, 5, 0.05
+    pos, vel, mass = generate_distribution("galaxy", n, 800.0, 0.07)
+    G, eps, theta = 0.07, 1.5, 0.5
+    single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, theta)
+    single.set_force_precision("f32")  # owner mode computes fp32 forces (no float64 node records on the wire yet)
+    single.step_many(dt, steps)
+    ref_p = single.get_positions_f64()
+    single.close()
+    L = oracle.lib()
+    L.nbref_set_num_threads(min(32, int(L.nbref_num_threads())))
+    ostep = oracle.BHStepper(pos, vel, mass, theta, G, eps, 1.0, cap=oracle.UNCAPPED, fast=False)
+    for _ in range(steps):
+        ostep.step(dt)
+    comm = _ThreadComm(world)
+    engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
+    assert all(e.stream is not None for e in engines)  # stream-ordered exchange is the default
+    steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    out = _run_ranks(steppers, comm, dt, steps)
+    scale = np.abs(ref_p).max()
+    err_single = np.abs(out[0][0] - ref_p).max() / scale
+    err_oracle = np.abs(out[0][0] - ostep.pos).max() / np.abs(ostep.pos).max()
+    rows = [int(e.let_counts.sum()) for e in engines]
+    print(f"owner mode, 1 M bodies x 8 ranks x {steps} steps: vs single handle {err_single:.2e}, vs oracle {err_oracle:.2e}; "
+          f"owned {[e.sim.n for e in engines]}, received tree rows {rows}")
+    assert err_single <= 1e-6 and err_oracle <= 1e-6
+    for r in range(1, world):
+        assert np.array_equal(out[r][0], out[0][0])
+    assert sum(e.sim.n for e in engines) == n
+    for e in engines:
+        e.sim.close()
