@@ -183,6 +183,12 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *   nbmi_owner_step(h, recv, recv_counts, dt)       append the received trees (packed in rank order, at most
  *                                                   let_capacity rows) behind the own one, walk, kick-drift
  *
+ * Host waits [r3]: with nbmi_set_exchange_sync(h, 0) and the collectives enqueued ON the handle's stream
+ * (nbmi_stream; torch.cuda.ExternalStream), nbmi_owner_maxabs / _sample / _adopt / _step only enqueue; the two
+ * calls that hand counts to the host wait once each (nbmi_owner_partition, nbmi_owner_export_let).  With the
+ * default sync = 1 every call waits for its own work, as in round 2.  World size 1 skips the splitter, dead-row
+ * and box work altogether.
+ *
  * Getters of an owner handle return the owned bodies in their current (key) order; nbmi_owner_get_ids gives the
  * global body ids of those rows. */
 nbmi_sim *nbmi_create_owner(int64_t n, const double *positions_xyz, const double *velocities_xyz, const double *masses,
@@ -208,9 +214,9 @@ int nbmi_owner_step(nbmi_sim *sim, const void *dev_recv_let, const int64_t *recv
  * part crosses PCIe. */
 int nbmi_visible_points(nbmi_sim *sim, const double *cam12, double tan_h, double tan_v, double far_dist,
                         float *out_positions_xyz, float *out_colors_rgb, int64_t capacity, int64_t *count);
-/* nbmi_export_shard / nbmi_import_ranks synchronise the handle's stream by default.  With sync = 0 they
- * only enqueue: for callers that issue their collective ON the handle's stream (nbmi_stream; e.g.
- * torch.cuda.ExternalStream), so that a step needs no host synchronisation at all. */
+/* nbmi_export_shard / nbmi_import_ranks and the nbmi_owner_* calls synchronise the handle's stream by default.
+ * With sync = 0 they only enqueue (except where a call returns counts to the host): for callers that issue
+ * their collective ON the handle's stream (nbmi_stream; e.g. torch.cuda.ExternalStream). */
 int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 
 /* Arithmetic of the Barnes-Hut pair forces (the accepted (body, node) sets are the reference's in every mode):
