@@ -801,6 +801,7 @@ struct WalkParams {
 
     float eps2;
     int xcd_chunk;  // see logical_block()
+    int balance;    // 1: blocks are dealt to the XCDs by last step's measured times (WalkTable::xcd_bounds)
     int pair;       // one-wave walk with two cursors (the two halves of the array)
     double dt, damping;
     int curbuf;  // which of WalkTable.buf holds the current state
@@ -819,6 +820,8 @@ struct WalkTable {
     Bodies buf[2];
     const Node64 *n64;
     const NodeD *nodesd;  // float64 node records (null: the handle computes every force in fp32)
+    const int *xcd_bounds;   // [9] logical walk blocks [b[x], b[x + 1]) belong to XCD x (balance mode)
+    unsigned *wave_cycles;   // [4 per logical block] how long each wave of the last walk took (shader clocks)
     const int32_t *pex, *subpex;  // leaf of the body at sorted rank r = node r + pex_at(pex, subpex, r + 1)
     unsigned long long *maxabs_next;  // TreeInfo::maxabs_next
     double theta, eps2;
@@ -1227,6 +1230,12 @@ __device__ __forceinline__ unsigned tie_visit64(const NodeD *nodesd, unsigned of
     return __builtin_amdgcn_readfirstlane(any_open ? off + kNodeDBytes : nd.next_off);
 }
 
+// a wave-uniform 64-bit value the compiler no longer knows to be uniform (loaded behind something it treats as a
+// possible store, e.g. the cycle counter read of the balance mode) back into scalar registers
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -1340,6 +1349,73 @@ __device__ __forceinline__ void publish_maxabs(const WalkTable *tab, double lane
     }
 }
 
+// [r3] Cuts for the balance mode of k_walk: XCD x gets the logical blocks [b[x], b[x + 1]) such that every range
+// holds about an eighth of last step's total wave time (bodies move little between steps), at most `jmax` blocks
+// (the launch has 8 jmax workgroups) and at least one.  One workgroup: per-thread chunk sums, scan, the seven
+// thread(s) whose chunk holds a cut find it.  All-zero times (first step) give equal ranges.
+__global__ __launch_bounds__(1024) void k_xcd_bounds(const unsigned *__restrict__ wave_cycles, int nb, int jmax, int *__restrict__ bounds) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long total_s;
+    __shared__ int cut[9];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int chunk = (nb + 1023) / 1024;
+    const int b = t * chunk < nb ? t * chunk : nb, e = b + chunk < nb ? b + chunk : nb;
+    unsigned long long acc = 0;
+    for (int i = b; i < e; i++) {
+        const uint4 q = reinterpret_cast<const uint4 *>(wave_cycles)[i];
+        acc += (unsigned long long)q.x + q.y + q.z + q.w + 1ull;  // + 1: all-zero input still cuts into equal parts
+    }
+    unsigned long long inc = acc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    unsigned long long off = 0, total = 0;
+    for (int q = 0; q < 16; q++) {
+        if (q < w) off += wsum[q];
+        total += wsum[q];
+    }
+    inc += off;
+    if (t == 0) { total_s = total; cut[0] = 0; cut[8] = nb; }
+    __syncthreads();
+    const unsigned long long ex = inc - acc;  // work before this thread's chunk
+    for (int k = 1; k < 8; k++) {
+        const unsigned long long target = total_s / 8ull * (unsigned long long)k;
+        if (b < e && ex <= target && target < inc) {
+            unsigned long long run = ex;
+            int i = b;
+            for (; i < e; i++) {
+                const uint4 q = reinterpret_cast<const uint4 *>(wave_cycles)[i];
+                run += (unsigned long long)q.x + q.y + q.z + q.w + 1ull;
+                if (run > target) break;
+            }
+            cut[k] = i + 1 < nb ? i + 1 : nb;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        // ranges of 1 .. jmax blocks, in order; what the clamps push out goes to the later XCDs
+        int prev = 0;
+        for (int k = 1; k < 8; k++) {
+            int c = cut[k];
+            const int lo = prev + 1, hi = prev + jmax;
+            const int need_after = (8 - k);  // blocks the remaining XCDs need at least ...
+            const int room_after = (8 - k) * jmax;  // ... and can take at most
+            if (c < lo) c = lo;
+            if (c > hi) c = hi;
+            if (nb - c < need_after) c = nb - need_after;
+            if (nb - c > room_after) c = nb - room_after;
+            bounds[k] = c;
+            prev = c;
+        }
+        bounds[0] = 0;
+        bounds[8] = nb;
+    }
+}
+
 // The walk kernel.  kCount = parity/measurement build (C++ visit, work counters);
 // otherwise the hand-scheduled loop (eps > 0) or the C++ visit with the distance guard (eps == 0).
 template <bool kIntegrate, bool kCount, bool kGuard>
@@ -1347,7 +1423,22 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
                                                  const TreeInfo *info_in, const float4 *__restrict__ posm_s,
                                                  const uint32_t *__restrict__ perm,
                                                  double *__restrict__ acc_out, WalkParams P, TreeInfo *info_out) {
-    const int lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    // [r3] Which logical block (= which 256 consecutive ranks) this workgroup walks.  Hardware deals workgroups to the
+    // eight XCDs round-robin; logical_block() gives every XCD one contiguous eighth of the blocks (neighbouring
+    // groups walk the same nodes: L2 locality) - equal in blocks, not in work: the XCD that got the densest part
+    // of the system sets the kernel's time (10 M collision: the busiest XCD has 5.5 % more visits than the mean).
+    // Balance mode keeps the contiguous ranges but cuts them where last step's measured wave times say an eighth of
+    // the WORK ends (k_xcd_bounds); a workgroup beyond its XCD's range has nothing to do.
+    int lb;
+    if (kIntegrate && P.balance) {
+        const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+        const int b0 = __builtin_amdgcn_readfirstlane(tab->xcd_bounds[xcd]);
+        const int b1 = __builtin_amdgcn_readfirstlane(tab->xcd_bounds[xcd + 1]);
+        lb = b0 + jb;
+        if (lb >= b1) return;
+    } else {
+        lb = logical_block(blockIdx.x, gridDim.x, P.xcd_chunk);
+    }
     const int lane = threadIdx.x & 63;
     const int64_t rank = P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x;
     const bool valid = rank < P.rank_end;
@@ -1390,15 +1481,18 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         }
         use64 = __builtin_amdgcn_readfirstlane((int)use64) != 0;
     }
+    // (the clock is read here, behind the prologue's loads: the compiler treats the read as a possible store and
+    // turns every scalar load that follows it into a vector load)
+    const unsigned long long t_start = (kIntegrate && P.balance) ? __builtin_readcyclecounter() : 0ull;
     if (use64) {
-        const NodeD *nodesd = tab->nodesd;
+        const NodeD *nodesd = reinterpret_cast<const NodeD *>(uniform_u64(reinterpret_cast<unsigned long long>(tab->nodesd)));
         double qx = 0.0, qy = 0.0, qz = 0.0;
         if (valid) {
             const Bodies &cur = tab->buf[P.curbuf];
             qx = cur.x[j]; qy = cur.y[j]; qz = cur.z[j];
         }
-        const double eps2d = tab->eps2;
-        const unsigned nnd = frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeDBytes);
+        const double eps2d = __longlong_as_double((long long)uniform_u64((unsigned long long)__double_as_longlong(tab->eps2)));
+        const unsigned nnd = __builtin_amdgcn_readfirstlane(frozen ? 0u : ((unsigned)info_in->walk_nodes * kNodeDBytes));
         unsigned off = 0u;
         while (off < nnd) {
             unsigned which = 0u;
@@ -1486,6 +1580,10 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     }
     if (kIntegrate) {
         publish_maxabs(tab, valid ? integrate(tab, j, rank, sx + (double)ax, sy + (double)ay, sz + (double)az, P, frozen) : 0.0);
+        if (P.balance && lane == 0) {
+            const unsigned long long dtc = __builtin_readcyclecounter() - t_start;
+            tab->wave_cycles[4 * lb + (threadIdx.x >> 6)] = (unsigned)(dtc > 0xffffffffull ? 0xffffffffull : dtc);
+        }
     } else if (valid) {
         const int64_t o = 3 * (int64_t)tab->buf[P.curbuf].id[j];
         const bool d64 = kCount && P.acc64;
@@ -2562,6 +2660,10 @@ struct nbmi_sim {
     uint8_t *vis_flag = nullptr;
     uint32_t *vis_slot = nullptr, *vis_tiles = nullptr;
     int xcd_chunk = 0;  // walk block -> XCD mapping, see logical_block()
+    int xcd_balance = 1;  // XCD ranges cut by last step's measured wave times (NBMI_XCD_BALANCE=0: equal eighths)
+    int *xcd_bounds = nullptr;        // device [9]
+    unsigned *wave_cycles = nullptr;  // device [4 per walk block]
+    int balance_blocks = 0;           // the block count the bounds on the device were made for (0: none yet)
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
     bool maxabs_fused = false;  // TreeInfo::maxabs_next holds max |coordinate| of the CURRENT positions (set by a full
@@ -2611,6 +2713,8 @@ int upload_walk_table(nbmi_sim *s) {
     t.buf[1] = s->buf[1];
     t.n64 = s->nodes64;
     t.nodesd = s->nodesd;
+    t.xcd_bounds = s->xcd_bounds;
+    t.wave_cycles = s->wave_cycles;
     t.pex = s->Pex;
     t.subpex = s->subPex;
     t.maxabs_next = &s->info->maxabs_next;
@@ -2750,6 +2854,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
     P.curbuf = s->curbuf;
     P.acc64 = getenv("NBMI_ACC64") ? atoi(getenv("NBMI_ACC64")) : 0;
+    P.balance = 0;
     P.force_prec = s->nodesd ? s->force_prec : 1;
     P.prec_tau = (float)s->prec_tau;
     P.prec = s->prec;
@@ -2793,6 +2898,25 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     }
 #define NBMI_WALK(I, C, G) \
     k_walk<I, C, G><<<gb, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, acc_out, P, s->info)
+    // balance mode: full, unsharded integrating walks of the product kernel with the default block mapping
+    // (measured: 10 M collision walk 15.9 -> 14.8 ms, fp32 10.4 -> 9.8; 4 M galaxy 6.96 -> 6.90; at 1 M bodies the eighths are
+    // within 1 % of each other already and the half-empty launch costs 2 %: from 8 192 blocks = 2 M bodies on)
+    const bool balance = integrate && !guard && s->xcd_balance && s->xcd_chunk == 0 && wb == kBlock && !s->owner &&
+                         (gb >= 8192 || s->xcd_balance > 1) &&
+                         P.rank_begin == 0 && P.rank_end == n && getenv("NBMI_XCD_CHUNK") == nullptr;
+    if (balance) {
+        const int jmax = ((gb + 7) / 8) * 3 / 2 + 1;
+        if (s->balance_blocks != gb) {  // first use (or another shard size): no times yet -> equal eighths
+            NBMI_HIP_CHECK(hipMemsetAsync(s->wave_cycles, 0, (size_t)gb * 16, st));
+            k_xcd_bounds<<<1, 1024, 0, st>>>(s->wave_cycles, gb, jmax, s->xcd_bounds);
+            s->balance_blocks = gb;
+        }
+        P.balance = 1;
+        k_walk<true, false, false><<<8 * jmax, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, acc_out, P, s->info);
+        k_xcd_bounds<<<1, 1024, 0, st>>>(s->wave_cycles, gb, jmax, s->xcd_bounds);  // cuts for the next step
+        NBMI_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (integrate) {
         if (guard) NBMI_WALK(true, false, true); else NBMI_WALK(true, false, false);
     } else {
@@ -2903,6 +3027,7 @@ void nbmi_destroy(nbmi_sim *s) {
 // measurement / tuning knobs, read once per handle by both constructors
 static void read_env_knobs(nbmi_sim *s) {
     if (const char *e = getenv("NBMI_XCD_CHUNK")) s->xcd_chunk = atoi(e);
+    if (const char *e = getenv("NBMI_XCD_BALANCE")) s->xcd_balance = atoi(e);
     if (const char *e = getenv("NBMI_SPLIT_WAVES")) s->split_max_waves = atoll(e);
     if (const char *e = getenv("NBMI_WALK_PAIR")) s->walk_pair = atoi(e);
     if (const char *e = getenv("NBMI_FUSE_MAXABS")) s->fuse_maxabs = atoi(e) != 0;
@@ -2954,6 +3079,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             dev_alloc(s, &s->node_level, own_rows) || dev_alloc(s, &s->node_ref, own_rows) ||
             (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
             (s->prec && dev_alloc(s, &s->diag64, own_rows)) ||
+            dev_alloc(s, &s->xcd_bounds, 16) || dev_alloc(s, &s->wave_cycles, (size_t)4 * ((c + 63) / 64 + 8)) ||
             (s->force_prec != 1 && !s->owner && s->softening > 1e-12 && s->node_capacity + 2 <= kMaxNodeDRows &&
              dev_alloc(s, &s->nodesd, s->node_capacity + 2)) ||
             false)
