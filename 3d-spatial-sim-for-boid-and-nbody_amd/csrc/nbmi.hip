@@ -124,6 +124,10 @@ struct TreeInfo {
     // of 10 is still there when the host looks (nbmi_sync / getters), which reports and clears it.
     int sticky_error;
     long long sticky_nodes;  // num_nodes of the build that overflowed
+    // force precision "auto": 1 when more than half of the last walk's waves chose float64 - then every wave does
+    // (k_flag_share; outside the ranges the per-step header reset clears)
+    int force_all64;
+    int pad1;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -399,8 +403,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
                                                         double4 *__restrict__ p64_s /* may be null */, uint64_t *__restrict__ lo_s,
                                                         int32_t *__restrict__ delta, double4 *__restrict__ S,
                                                         int32_t *__restrict__ PexL, double4 *__restrict__ sub_tot,
-                                                        int32_t *__restrict__ sub_cnt) {
+                                                        int32_t *__restrict__ sub_cnt, unsigned char *__restrict__ wave_flag,
+                                                        int32_t *__restrict__ sub_flag, float dens_thr, float edge_floor) {
     __shared__ Mom4 wtot[kBlock / 64];
+    __shared__ int wflag[kBlock / 64];
+    int nflag = 0;  // (thread 0) waves of this tile whose density asks for float64 forces
     __shared__ int dl[kBlock + 1];  // delta of the round's ranks, dl[0] = delta of the rank before the round
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     Mom4 carry{0.0, 0.0, 0.0, 0.0, 0};  // the rounds before this one (plain float64: at most 2047 terms)
@@ -412,9 +419,11 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
         Mom4 v{0.0, 0.0, 0.0, 0.0, 0};
         int d = -1;
         uint64_t h = 0, l = 0;
+        float fx = 0.f, fy = 0.f, fz = 0.f;
         if (r < n) {
             const uint32_t j = perm[r];
             const double x = cur.x[j], y = cur.y[j], z = cur.z[j], gm = G * cur.m[j];
+            fx = (float)x; fy = (float)y; fz = (float)z;
             posm_s[r] = make_float4((float)x, (float)y, (float)z, (float)gm);
             if (p64_s) p64_s[r] = make_double4(x, y, z, gm);
             h = hi_s[r];
@@ -426,6 +435,33 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
             }
             delta[r] = d;
             v = Mom4{gm, gm * x, gm * y, gm * z, 0};
+        }
+        if (wave_flag) {
+            // [r3] force precision "auto", decided here where the sorted bodies pass through registers: G rho of the
+            // DENSEST quarter of the wave (16 key-adjacent bodies: sum of G m over the volume of their bounding box, every
+            // edge at least one softening length) against tau / dt^2.  Not the whole wave's box: 64 consecutive bodies
+            // of the key order can straddle a gap (the two disks of the collision preset, a cell boundary high up in the
+            // tree) and their common box then says nothing about where they sit.
+            const bool have = r < n;
+            const float big = 3.0e38f;
+            float lox = have ? fx : big, hix = have ? fx : -big, loy = have ? fy : big, hiy = have ? fy : -big;
+            float loz = have ? fz : big, hiz = have ? fz : -big, gsum = have ? (float)v.m : 0.f;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                lox = fminf(lox, __shfl_xor(lox, o)); hix = fmaxf(hix, __shfl_xor(hix, o));
+                loy = fminf(loy, __shfl_xor(loy, o)); hiy = fmaxf(hiy, __shfl_xor(hiy, o));
+                loz = fminf(loz, __shfl_xor(loz, o)); hiz = fmaxf(hiz, __shfl_xor(hiz, o));
+                gsum += __shfl_xor(gsum, o);
+            }
+            const float vol = fmaxf(hix - lox, edge_floor) * fmaxf(hiy - loy, edge_floor) * fmaxf(hiz - loz, edge_floor);
+            float dens = gsum > 0.f ? gsum / vol : 0.f;
+            dens = fmaxf(dens, __shfl_xor(dens, 16));
+            dens = fmaxf(dens, __shfl_xor(dens, 32));
+            const int flag = dens > dens_thr ? 1 : 0;
+            if (lane == 0) {
+                if (r0 + 64 * w < n) wave_flag[(r0 >> 6) + w] = (unsigned char)flag;
+                wflag[w] = (r0 + 64 * w < n) ? flag : 0;
+            }
         }
         dl[t + 1] = d;
         if (t == 0) {
@@ -450,6 +486,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
         }
         if (lane == 63) wtot[w] = inc;
         __syncthreads();
+        if (wave_flag && t == 0) nflag += wflag[0] + wflag[1] + wflag[2] + wflag[3];
         Mom4 off = carry, tot{0.0, 0.0, 0.0, 0.0, 0};
 #pragma unroll
         for (int q = 0; q < kBlock / 64; q++) {
@@ -471,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
     if (t == 0) {
         sub_tot[blockIdx.x] = make_double4(carry.m, carry.x, carry.y, carry.z);
         sub_cnt[blockIdx.x] = carry.c;
+        if (wave_flag) sub_flag[blockIdx.x] = nflag;
     }
 }
 
@@ -492,15 +530,29 @@ __device__ __forceinline__ SubVal sub_shfl_up(const SubVal &v, int d) {
 }
 __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4 *__restrict__ sub_tot,
                                                                    const int32_t *__restrict__ sub_cnt, int64_t nsub,
-                                                                   Moment *__restrict__ T, int32_t *__restrict__ subPex) {
+                                                                   Moment *__restrict__ T, int32_t *__restrict__ subPex,
+                                                                   const int32_t *__restrict__ sub_flag, int64_t nwaves,
+                                                                   TreeInfo *info) {
     __shared__ SubVal wsum[kSubScanThreads / 64];
+    __shared__ long long fsum[kSubScanThreads / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t chunk = (nsub + kSubScanThreads - 1) / kSubScanThreads;
     const int64_t b = (int64_t)t * chunk, e = b + chunk < nsub ? b + chunk : nsub;
     SubVal acc = sub_zero();
+    long long fl = 0;
     for (int64_t i = b; i < e; i++) {
         const double4 q = sub_tot[i];
         acc = sub_add(acc, SubVal{{q.x, 0.0}, {q.y, 0.0}, {q.z, 0.0}, {q.w, 0.0}, (long long)sub_cnt[i]});
+        if (sub_flag) fl += sub_flag[i];
+    }
+    if (sub_flag) {
+        // [r3] force precision "auto": when more than half of the waves ask for float64, every wave gets it - where
+        // most of the system needs float64, the sparse rest interacts with the same massive cells (10 M collision at
+        // dt 0.25: the 5 % of the waves below any density threshold end at 3.8e-4 after 50 steps in fp32, at 1e-10 in
+        // float64; at the 1 M galaxy 30 % of the waves ask and the fp32 rest stays at 2e-6 after 100 steps)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) fl += __shfl_xor(fl, o);
+        if (lane == 0) fsum[w] = fl;
     }
     SubVal inc = acc;
 #pragma unroll
@@ -510,6 +562,11 @@ __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
+    if (sub_flag && t == 0) {
+        long long tot = 0;
+        for (int q = 0; q < kSubScanThreads / 64; q++) tot += fsum[q];
+        info->force_all64 = 2 * tot > nwaves ? 1 : 0;
+    }
     SubVal off = sub_zero();
     for (int q = 0; q < w; q++) off = sub_add(off, wsum[q]);
     SubVal run = sub_shfl_up(inc, 1);
@@ -822,6 +879,7 @@ struct WalkTable {
     const NodeD *nodesd;  // float64 node records (null: the handle computes every force in fp32)
     const int *xcd_bounds;   // [9] logical walk blocks [b[x], b[x + 1]) belong to XCD x (balance mode)
     unsigned *wave_cycles;   // [4 per logical block] how long each wave of the last walk took (shader clocks)
+    unsigned char *wave_flag;  // [one per wave] 1 = the wave's own density asked for float64 forces (auto mode)
     const int32_t *pex, *subpex;  // leaf of the body at sorted rank r = node r + pex_at(pex, subpex, r + 1)
     unsigned long long *maxabs_next;  // TreeInfo::maxabs_next
     double theta, eps2;
@@ -1462,22 +1520,16 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
     double acc64x = 0.0, acc64y = 0.0, acc64z = 0.0;
 
     // [r3] force precision of this wave (see NBMI_V64_X).  force_prec 0: float64 where the bodies' own neighbourhood is
-    // dense enough that an error, once made, is amplified within a few hundred steps - G rho dt^2 of the wave's 64
-    // bodies (sum of G m over the volume of their bounding box, every edge at least one softening length) above
-    // prec_tau.  All lanes of a wave agree; which 64 ranks form a wave does not depend on the sharding.
+    // dense enough that an error, once made, is amplified within a few hundred steps (decided in k_gather_scan, which
+    // has the sorted bodies in registers anyway), or where most of the system is.  All lanes of a wave agree; which
+    // 64 ranks form a wave does not depend on the sharding.
     bool use64 = false;
     if (!kCount && !kGuard && kIntegrate && tab->nodesd && P.force_prec != 1) {
         if (P.force_prec == 2) {
             use64 = true;
         } else {
-            const float big = 3.0e38f;
-            const float ex = wave_max_f(valid ? C.px : -big) - wave_min_f(valid ? C.px : big);
-            const float ey = wave_max_f(valid ? C.py : -big) - wave_min_f(valid ? C.py : big);
-            const float ez = wave_max_f(valid ? C.pz : -big) - wave_min_f(valid ? C.pz : big);
-            const float gm_sum = wave_sum_f(valid ? posm_s[rank].w : 0.f);
-            const float fl = sqrtf(P.eps2);
-            const float vol = fmaxf(ex, fl) * fmaxf(ey, fl) * fmaxf(ez, fl);
-            use64 = gm_sum * (float)(P.dt * P.dt) > P.prec_tau * vol;
+            // k_gather_scan has already decided, wave by wave (and k_scan_subtiles for the system as a whole)
+            use64 = tab->wave_flag[(P.rank_begin + (int64_t)lb * blockDim.x + threadIdx.x) >> 6] != 0 || info_in->force_all64 != 0;
         }
         use64 = __builtin_amdgcn_readfirstlane((int)use64) != 0;
     }
@@ -2617,7 +2669,7 @@ struct nbmi_sim {
     Node64 *nodes64 = nullptr;  // float64 twin rows of the internal cells (near-tie re-decision)
     NodeD *nodesd = nullptr;    // float64 node records of every node (waves that compute forces in float64)
     int force_prec = 0;         // 0 = per wave by local density, 1 = fp32 everywhere, 2 = float64 everywhere (NBMI_FORCE_PREC)
-    double prec_tau = 1.0e-5;   // force_prec 0: float64 where G rho dt^2 exceeds this (NBMI_PREC_TAU)
+    double prec_tau = 5.0e-5;   // force_prec 0: float64 where G rho dt^2 exceeds this (NBMI_PREC_TAU)
     WalkTable *wtab = nullptr;  // device copy of the walk's per-handle constants
     uint8_t *node_level = nullptr;
     int32_t *node_ref = nullptr;  // first body (sorted rank) of every node; queries only
@@ -2663,6 +2715,9 @@ struct nbmi_sim {
     int xcd_balance = 1;  // XCD ranges cut by last step's measured wave times (NBMI_XCD_BALANCE=0: equal eighths)
     int *xcd_bounds = nullptr;        // device [9]
     unsigned *wave_cycles = nullptr;  // device [4 per walk block]
+    unsigned char *wave_flag = nullptr;  // device [one per wave]
+    int32_t *sub_flag = nullptr;         // device [one per tile]: waves of the tile that ask for float64
+    double step_dt = 0.0;                // dt of the step being enqueued (0: a build without a step)
     int balance_blocks = 0;           // the block count the bounds on the device were made for (0: none yet)
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
@@ -2715,6 +2770,7 @@ int upload_walk_table(nbmi_sim *s) {
     t.nodesd = s->nodesd;
     t.xcd_bounds = s->xcd_bounds;
     t.wave_cycles = s->wave_cycles;
+    t.wave_flag = s->wave_flag;
     t.pex = s->Pex;
     t.subpex = s->subPex;
     t.maxabs_next = &s->info->maxabs_next;
@@ -2764,6 +2820,9 @@ int enqueue_maxabs(nbmi_sim *s) {
 
 // n_sort rows are keyed and sorted (owner mode: rows of emigrants are still in place, flagged dead, and sort to
 // the end); the first n_live of the order are gathered for the tree
+// force precision "auto" is decided during the build of a step (it needs dt); anything else leaves the flags alone
+static inline bool auto_prec(const nbmi_sim *s) { return s->nodesd && s->force_prec == 0 && s->step_dt > 0.0; }
+
 int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_live = -1, const uint8_t *dead = nullptr) {
     const int64_t n = n_sort < 0 ? s->n : n_sort;
     if (n_live < 0) n_live = n;
@@ -2796,7 +2855,9 @@ int enqueue_local_sort(nbmi_sim *s, int ev_base, int64_t n_sort = -1, int64_t n_
     if (ev_base >= 0) NBMI_HIP_CHECK(hipEventRecord(s->ev[2], st));
     // ranks 0 .. n_live: entry n_live is the slot of the totals
     k_gather_scan<<<(int)((n_live + 1 + kScanTile - 1) / kScanTile), kBlock, 0, st>>>(
-        cur, s->perm, s->hi_s, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s, s->delta, s->S, s->Pex, s->sub_tot, s->sub_cnt);
+        cur, s->perm, s->hi_s, s->key_lo, n_live, s->G, s->posm_s, s->p64_s, s->lo_s, s->delta, s->S, s->Pex, s->sub_tot, s->sub_cnt,
+        auto_prec(s) ? s->wave_flag : nullptr, s->sub_flag, auto_prec(s) ? (float)(s->prec_tau / (s->step_dt * s->step_dt)) : 0.f,
+        (float)s->softening);
     return 0;
 }
 
@@ -2806,7 +2867,8 @@ int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
     hipStream_t st = s->stream;
     // (delta, the in-sub-tile prefixes S / PexL and the sub-tile totals: written by k_gather_scan)
     const int64_t nsub = (n + 1 + kScanTile - 1) / kScanTile;  // sub-tiles that hold the entries 0 .. n
-    k_scan_subtiles<<<1, kSubScanThreads, 0, st>>>(s->sub_tot, s->sub_cnt, nsub, s->T, s->subPex);
+    k_scan_subtiles<<<1, kSubScanThreads, 0, st>>>(s->sub_tot, s->sub_cnt, nsub, s->T, s->subPex,
+                                                   auto_prec(s) ? s->sub_flag : nullptr, (n + 63) / 64, s->info);
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     k_emit_tile<<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
@@ -3080,6 +3142,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             (s->walk_stack && dev_alloc(s, &s->child_tab, (size_t)8 * own_rows)) ||
             (s->prec && dev_alloc(s, &s->diag64, own_rows)) ||
             dev_alloc(s, &s->xcd_bounds, 16) || dev_alloc(s, &s->wave_cycles, (size_t)4 * ((c + 63) / 64 + 8)) ||
+            dev_alloc(s, &s->wave_flag, (size_t)(c + 63) / 64 + 64) || dev_alloc(s, &s->sub_flag, (c + 1) / kScanTile + 2) ||
             (s->force_prec != 1 && !s->owner && s->softening > 1e-12 && s->node_capacity + 2 <= kMaxNodeDRows &&
              dev_alloc(s, &s->nodesd, s->node_capacity + 2)) ||
             false)
@@ -3219,7 +3282,10 @@ int nbmi_step(nbmi_sim *s, double dt, int substeps) {
     for (int k = 0; k < substeps; k++) {
         if (s->method == NBMI_METHOD_BARNES_HUT) {
             const int evb = s->timers ? 0 : -1;
-            if (int rc = enqueue_tree(s, evb, false)) return rc;
+            s->step_dt = dt;
+            const int rc_tree = enqueue_tree(s, evb, false);
+            s->step_dt = 0.0;
+            if (rc_tree) return rc_tree;
             if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
             if (s->timers) {
                 NBMI_HIP_CHECK(hipEventRecord(s->ev[4], s->stream));
@@ -3995,6 +4061,27 @@ int nbmi_set_force_precision(nbmi_sim *s, int mode, double tau) {
     }
     s->force_prec = mode;
     if (mode == 0 && tau > 0.0) s->prec_tau = tau;
+    return 0;
+}
+
+int nbmi_force_precision_share(nbmi_sim *s, double *share, int *all64) {
+    if (int rc = check_handle(s)) return rc;
+    if (!share || !all64) { nbmi::set_error("nbmi_force_precision_share: null output"); return NBMI_ERR_ARG; }
+    *share = 0.0;
+    *all64 = 0;
+    if (s->method != NBMI_METHOD_BARNES_HUT || !s->nodesd || s->n == 0) return 0;
+    if (s->force_prec == 2) { *share = 1.0; *all64 = 1; return 0; }
+    if (s->force_prec == 1) return 0;
+    const int64_t nw = (s->n + 63) / 64;
+    std::vector<unsigned char> h((size_t)nw);
+    TreeInfo ti;
+    NBMI_HIP_CHECK(hipMemcpyAsync(h.data(), s->wave_flag, (size_t)nw, hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipMemcpyAsync(&ti, s->info, sizeof(ti), hipMemcpyDeviceToHost, s->stream));
+    NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    int64_t c = 0;
+    for (int64_t i = 0; i < nw; i++) c += h[i] ? 1 : 0;
+    *share = (double)c / (double)nw;
+    *all64 = ti.force_all64;
     return 0;
 }
 

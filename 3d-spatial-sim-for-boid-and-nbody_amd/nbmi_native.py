@@ -60,6 +60,7 @@ PROTOTYPES = {
     "nbmi_visible_points": (C.c_int, [_vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),
     "nbmi_set_exchange_sync": (C.c_int, [_vp, C.c_int]),
     "nbmi_set_force_precision": (C.c_int, [_vp, C.c_int, _dbl]),
+    "nbmi_force_precision_share": (C.c_int, [_vp, _vp, _vp]),
     "nbmi_stream": (_vp, [_vp]),
     "nbmi_frame_keyframe": (C.c_int, [_vp, _vp, _vp]),
     "nbmi_frame_delta_i16": (C.c_int, [_vp, _vp, _vp]),

@@ -270,6 +270,13 @@ class HIPBarnesHutSimulation(_HIPSimulation):
     def build_tree(self):
         _nat.check(self._lib.nbmi_build_tree(self._h), "nbmi_build_tree")
 
+    def force_precision_share(self):
+        """(share of the waves whose own density asked for float64 forces in the last step, every wave float64?)"""
+        share, all64 = C.c_double(0.0), C.c_int(0)
+        _nat.check(self._lib.nbmi_force_precision_share(self._h, C.addressof(share), C.addressof(all64)),
+                   "nbmi_force_precision_share")
+        return float(share.value), bool(all64.value)
+
     FORCE_PRECISION = {"auto": 0, "f32": 1, "f64": 2}
 
     def set_force_precision(self, mode="auto", tau=0.0):

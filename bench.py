@@ -436,8 +436,9 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": ("f64 pair forces for the waves of 64 bodies whose G*rho*dt^2 > 1e-5 (library default), f32 pair forces with f64 "
-                  "sums for the others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
+        "dtype": ("f64 pair forces for the waves of 64 bodies whose densest quarter has G*rho*dt^2 > 5e-5 - and for every wave "
+                  "once more than half of them qualify (library default 'auto') -, f32 pair forces with f64 sums for the "
+                  "others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
                  else "f32 pair forces, f64 sums/state",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": workload, "distribution": dist_name.replace("_fast", ""),
@@ -503,6 +504,9 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
             out["roofline"] = {"bound": "fp32-valu", "kernel": "k_direct", "achieved": ach, "peak": 157.3,
                                "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None, "kernel_ms": walk_ms,
                                "interactions_per_s": n_total * n_total / (walk_ms * 1e-3)}
+        if method == "barnes_hut":
+            share, all64 = sim.force_precision_share()
+            out["config"]["float64_wave_share"] = {"asked": round(share, 4), "every_wave_float64": all64}
         if method == "barnes_hut" and workload == args.workload:
             out["frame_pcie"] = frame_rates(sim, dt, n_total)
         if not args.no_cpu_baseline:

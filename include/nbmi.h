@@ -220,14 +220,20 @@ int nbmi_visible_points(nbmi_sim *sim, const double *cam12, double tan_h, double
 int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 
 /* Arithmetic of the Barnes-Hut pair forces (the accepted (body, node) sets are the reference's in every mode):
- *   0  per wave of 64 key-adjacent bodies: float64 where G rho dt^2 of the wave's bodies exceeds `tau`
- *      (default 1e-5; tau = 0 keeps the current value), fp32 elsewhere.  Default.  The reference computes in
- *      float64 throughout (nbody/simulation.py:246-268); in the dense inner part of a system fp32's systematic
- *      roundings are amplified to > 1e-4 of the largest coordinate within 100 steps.
+ *   0  per wave of 64 key-adjacent bodies: float64 where G rho dt^2 of the wave's densest quarter (16 bodies: sum of
+ *      G m over the volume of their bounding box, every edge at least one softening length) exceeds `tau`
+ *      (default 5e-5; tau = 0 keeps the current value), fp32 elsewhere - and float64 for EVERY wave of a step in
+ *      which more than half of the waves qualify.  Default.  The reference computes in float64 throughout
+ *      (nbody/simulation.py:246-268); in the dense part of a system fp32's systematic roundings are amplified to
+ *      > 1e-4 of the largest coordinate within 100 steps, and where most of the system is that dense the rest
+ *      follows.
  *   1  fp32 everywhere (float64 sums): fastest.
  *   2  float64 everywhere: follows the reference to ~1e-13 over 100 steps at 1 M bodies.
  * Environment NBMI_FORCE_PREC / NBMI_PREC_TAU set the initial values. */
 int nbmi_set_force_precision(nbmi_sim *sim, int mode, double tau);
+/* Mode 0, after a step: the share of the waves whose own density asked for float64, and whether the step ran every
+ * wave in float64 (more than half asked). */
+int nbmi_force_precision_share(nbmi_sim *sim, double *share, int *all_float64);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
 
