@@ -397,6 +397,14 @@ __device__ __forceinline__ Mom4 m4_shfl_up(const Mom4 &v, int d) {
     return Mom4{__shfl_up(v.m, d), __shfl_up(v.x, d), __shfl_up(v.y, d), __shfl_up(v.z, d), __shfl_up(v.c, d)};
 }
 
+// lane exchange inside a row of 16 lanes as a DPP operand (CTRL: 0xB1 / 0x4E quad_perm [1,0,3,2] / [2,3,0,1], 0x141
+// row_half_mirror, 0x140 row_mirror)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float add_f(float a, float b) { return a + b; }
+
 __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32_t *__restrict__ perm,
                                                         const uint64_t *__restrict__ hi_s, const uint64_t *__restrict__ key_lo,
                                                         int64_t n, double G, float4 *__restrict__ posm_s,
@@ -446,13 +454,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_scan(Bodies cur, const uint32
             const float big = 3.0e38f;
             float lox = have ? fx : big, hix = have ? fx : -big, loy = have ? fy : big, hiy = have ? fy : -big;
             float loz = have ? fz : big, hiz = have ? fz : -big, gsum = have ? (float)v.m : 0.f;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                lox = fminf(lox, __shfl_xor(lox, o)); hix = fmaxf(hix, __shfl_xor(hix, o));
-                loy = fminf(loy, __shfl_xor(loy, o)); hiy = fmaxf(hiy, __shfl_xor(hiy, o));
-                loz = fminf(loz, __shfl_xor(loz, o)); hiz = fmaxf(hiz, __shfl_xor(hiz, o));
-                gsum += __shfl_xor(gsum, o);
-            }
+            // butterflies inside a row of 16 lanes as DPP operands (quad swaps, half-row mirror, row mirror: min, max and
+            // the sum are symmetric) - one vector instruction each, where __shfl_xor is an LDS round trip (28 of them per
+            // round cost 0.15 ms at 10 M bodies)
+#define NBMI_ROW16(V, OP)                      \
+    V = OP(V, dpp_f<0xB1>(V));                 \
+    V = OP(V, dpp_f<0x4E>(V));                 \
+    V = OP(V, dpp_f<0x141>(V));                \
+    V = OP(V, dpp_f<0x140>(V));
+            NBMI_ROW16(lox, fminf) NBMI_ROW16(hix, fmaxf) NBMI_ROW16(loy, fminf) NBMI_ROW16(hiy, fmaxf)
+            NBMI_ROW16(loz, fminf) NBMI_ROW16(hiz, fmaxf) NBMI_ROW16(gsum, add_f)
+#undef NBMI_ROW16
             const float vol = fmaxf(hix - lox, edge_floor) * fmaxf(hiy - loy, edge_floor) * fmaxf(hiz - loz, edge_floor);
             float dens = gsum > 0.f ? gsum / vol : 0.f;
             dens = fmaxf(dens, __shfl_xor(dens, 16));
@@ -1250,6 +1262,37 @@ __device__ __forceinline__ void walk4_asm64(const NodeD *nodesd, unsigned &off, 
                    "s66", "vcc", "scc", "memory");
 }
 
+// the same with one visit per loop test: a part of the array must not be stepped past (split walk)
+__device__ __forceinline__ void walk1_asm64(const NodeD *nodesd, unsigned &off, unsigned end, double px, double py,
+                                            double pz, double eps2, unsigned band2, unsigned &resume, double &sx,
+                                            double &sy, double &sz, unsigned &which) {
+    double dx, dy, dz, d2, y0, t, w;
+    float d2f;
+    const double c15 = 1.5;
+    asm volatile("s_load_dwordx8 s[36:43], %[base], %[off]\n"
+                 "s_load_dwordx2 s[44:45], %[base], %[off] offset:32\n"
+                 "1:\n" NBMI_V64_A("21", "31", "51")
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc0 9f\n" NBMI_V64_B("22", "32", "52")
+                 "s_cmp_lt_u32 %[off], %[end]\n"
+                 "s_cbranch_scc1 1b\n"
+                 "s_branch 9f\n"
+                 NBMI_O64_A("21", "31", "51") NBMI_O64_B("22", "32", "52")
+                 "7:\n"
+                 "s_mov_b64 exec, -1\n"
+                 "s_mov_b32 %[which], 1\n"
+                 "9:\n"
+                 "s_waitcnt lgkmcnt(0)\n"
+                 : [off] "+s"(off), [which] "+s"(which), [resume] "+v"(resume), [sx] "+v"(sx), [sy] "+v"(sy), [sz] "+v"(sz),
+                   [dx] "=&v"(dx), [dy] "=&v"(dy), [dz] "=&v"(dz), [d2] "=&v"(d2), [y0] "=&v"(y0), [t] "=&v"(t),
+                   [w] "=&v"(w), [d2f] "=&v"(d2f)
+                 : [base] "s"(nodesd), [px] "v"(px), [py] "v"(py), [pz] "v"(pz), [eps2] "s"(eps2), [c15] "s"(c15),
+                   [end] "s"(end), [band2] "s"(band2)
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+                   "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65",
+                   "s66", "vcc", "scc", "memory");
+}
+
 // one float64 visit in C++ with the float64 re-decision of the lanes inside the band (the asm loop stopped on this
 // node).  Operation for operation the asm visit: a body's sums do not depend on which of its visits came through here.
 __device__ __forceinline__ unsigned tie_visit64(const NodeD *nodesd, unsigned off, double qx, double qy, double qz,
@@ -1685,9 +1728,36 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     // wave-uniform range (w is the wave index): tell the compiler so
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * w / K) * kNodeBytes);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * (w + 1) / K) * kNodeBytes);
+    // [r3] force precision of the group (all K waves of the workgroup walk the same 64 bodies): as in k_walk
+    bool use64 = false;
+    if (tab->nodesd && P.force_prec != 1)
+        use64 = P.force_prec == 2 || tab->wave_flag[(P.rank_begin + (int64_t)lb * 64) >> 6] != 0 || info_in->force_all64 != 0;
+    use64 = __builtin_amdgcn_readfirstlane((int)use64) != 0;
     if (lo < hi) {
+        // (seek works on the fp32 records in both cases: it only replays opening decisions, and those are the same)
         const unsigned c0 = __builtin_amdgcn_readfirstlane(lo == 0u ? 0u : seek(C, P, lo, resume));
-        if (c0 < hi) walk_span<false>(C, P, c0, hi, resume, ax, ay, az, sx, sy, sz);
+        if (c0 < hi && !use64) {
+            walk_span<false>(C, P, c0, hi, resume, ax, ay, az, sx, sy, sz);
+        } else if (c0 < hi) {
+            const NodeD *nodesd = reinterpret_cast<const NodeD *>(uniform_u64(reinterpret_cast<unsigned long long>(tab->nodesd)));
+            double qx = 0.0, qy = 0.0, qz = 0.0;
+            if (valid) {
+                const Bodies &cur = tab->buf[P.curbuf];
+                qx = cur.x[j]; qy = cur.y[j]; qz = cur.z[j];
+            }
+            const double eps2d = __longlong_as_double((long long)uniform_u64((unsigned long long)__double_as_longlong(tab->eps2)));
+            // offsets of the 24-byte records -> offsets of the 40-byte ones (same node indices)
+            unsigned off = c0 / kNodeBytes * kNodeDBytes;
+            const unsigned end = hi / kNodeBytes * kNodeDBytes;
+            unsigned res64 = resume == 0xffffffffu ? resume : resume / kNodeBytes * kNodeDBytes;
+            while (off < end) {
+                unsigned which = 0u;
+                walk1_asm64(nodesd, off, end, qx, qy, qz, eps2d, C.band2, res64, sx, sy, sz, which);
+                off = __builtin_amdgcn_readfirstlane(off);
+                if (!__builtin_amdgcn_readfirstlane(which)) break;
+                off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, C.band2, C.b64, res64, sx, sy, sz);
+            }
+        }
     }
     part[w][0][lane] = sx + (double)ax; part[w][1][lane] = sy + (double)ay; part[w][2][lane] = sz + (double)az;
     __syncthreads();
@@ -2934,7 +3004,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     // fastest or within 5 % of it; beyond ~280 k bodies the one-wave walk wins
     int parts = 1;
     while (parts < 16 && tree_groups <= 4300 && tree_groups * parts * 2 <= s->split_max_waves) parts *= 2;
-    if (integrate && !guard && parts > 1 && P.force_prec != 2) {  // (the split walk is fp32 only)
+    if (integrate && !guard && parts > 1) {
 #define NBMI_SPLIT(KV) \
     k_walk_split<KV><<<(int)groups, 64 * KV, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, P)
         if (parts == 2) NBMI_SPLIT(2);
@@ -3832,6 +3902,7 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int
     if (s->last_nodes > 0 && !s->exchange_sync) {
         nn = s->last_nodes + s->last_nodes / 50 + 4096;
         if (nn > s->own_node_rows) nn = s->own_node_rows;
+        if (getenv("NBMI_LET_UNDERESTIMATE")) nn = s->last_nodes / 2;  // test hook: forces the "bound did not hold" repeat
     }
     for (int attempt = 0; attempt < 2; attempt++) {
         if (nn < 0) {

@@ -283,6 +283,42 @@ def test_long_run_of_equal_upper_key_words(gpu, oracle):
     sim.close()
 
 
+def test_tiles_with_more_nodes_than_one_emission_chunk(gpu, oracle):
+    """k_emit_tile emits a tile's nodes 4 096 at a time.  1 500 close pairs: every pair hangs under a chain of ~5 cells,
+    so a tile of 2 048 bodies owns ~7 000 nodes (two chunks; the row budget of 4N + 4096 still holds them) and the
+    chains' upper cells reach beyond their tile.  Node count, depth and the cell set must still equal the oracle's."""
+    rng = np.random.RandomState(5)
+    base = rng.uniform(-100, 100, (1500, 3))
+    pos = np.concatenate([base, base + rng.uniform(-1, 1, (1500, 3)) * 0.05], axis=0)
+    pos = np.ascontiguousarray(pos[rng.permutation(len(pos))])
+    m = rng.uniform(0.5, 2.0, len(pos))
+    sim = _bh(gpu, pos, np.zeros_like(pos), m, 0.1, 0.5, theta=0.5)
+    sim.build_tree()
+    st = sim.tree_stats()
+    b = oracle.compute_bounds(pos)
+    nd = oracle.NodeArrays(64 * len(pos))
+    nn = oracle.build_octree(pos, m, b, nd, cap=oracle.UNCAPPED)
+    level, key = oracle.tree_cells(nd, nn)
+    print("pairs:", st, "oracle nodes", nn, "depth", int(level.max()))
+    assert 2 * 4096 < nn <= 4 * len(pos) + 4096
+    assert st["bounds"] == b and st["num_nodes"] == nn and st["max_depth"] == int(level.max())
+    glevel, gkey = sim.cells()
+    keep, gkeep = level <= 21, glevel <= 21
+    assert np.array_equal(_sorted_cells(level[keep], key[keep]), _sorted_cells(glevel[gkeep], gkey[gkeep]))
+    # moments and links of those nodes: one float64 step against the oracle (the pairs sit 1e-3 ... 5e-2 apart at
+    # coordinates of ~100, so fp32 pair forces are only good to ~1e-3 here; float64 must follow to rounding level)
+    sim.set_force_precision("f64")
+    vel = np.zeros_like(pos)
+    o = oracle.BHStepper(pos, vel, m, 0.5, 0.1, 0.5, 1.0, cap=oracle.UNCAPPED, rows=64 * len(pos), fast=False)
+    o.step(0.05)
+    sim.step(0.05)
+    acc_scale = np.linalg.norm(o.vel / 0.05, axis=1).max()
+    err = np.abs(sim.get_positions_f64() - o.pos).max() / (acc_scale * 0.05 ** 2)
+    print(f"   one float64 step: acceleration-equivalent error {err:.2e}")
+    assert err <= 1e-9  # (positions of ~100 round at 1e-14: 7e-11 of |a| dt^2 is the floor of this measure)
+    sim.close()
+
+
 def test_coincident_bodies_terminate(gpu):
     """Exactly coincident bodies make the reference subdivide until its node cap; here the key
     runs out at 42 levels and both become leaves of the level-42 cell.  Must terminate."""
@@ -627,7 +663,12 @@ def test_force_precision_modes(gpu, oracle):
     assert err["f64"] <= 1e-12
     assert err["f64"] <= err["auto"] <= 1e-7
     assert err["f32"] <= 1e-6
-    # small system (split-walk size): "f64" must take the float64 loop there too
+    # "auto", in the one-wave kernel (320 k bodies) and in the split walk of smaller systems (100 k): some waves ask
+    # for float64 at config 2's step; with a step 20 times longer more than half of them do, and then every wave
+    # computes in float64 - bit for bit the "f64" handle
+    for nb in (320_000, 100_000):
+        _auto_against_f64(gpu, nb)
+    # small system: the split walk has the float64 loop too
     k = 20_000
     o2 = oracle.BHStepper(p[:k], v[:k], m[:k], 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED, fast=False)
     s2 = _bh(gpu, p[:k], v[:k], m[:k], 0.07, 1.5, theta=0.5)
@@ -639,6 +680,27 @@ def test_force_precision_modes(gpu, oracle):
     print("   20 k bodies, f64 forced, 10 steps:", e2)
     assert e2 <= 1e-12
     s2.close()
+
+
+def _auto_against_f64(gpu, nb):
+    from tools.presets import generate_distribution
+    np.random.seed(8)
+    pb, vb, mb = generate_distribution("galaxy", nb, 800.0, 0.07)
+    a = _bh(gpu, pb, vb, mb, 0.07, 1.5, theta=0.5)
+    a.step_many(0.05, 2)
+    share, all64 = a.force_precision_share()
+    print(f"   auto at dt 0.05: {share:.3f} of the waves ask for float64, every wave float64: {all64}")
+    assert 0.02 < share < 0.5 and not all64
+    a.close()
+    a, f = _bh(gpu, pb, vb, mb, 0.07, 1.5, theta=0.5), _bh(gpu, pb, vb, mb, 0.07, 1.5, theta=0.5)
+    f.set_force_precision("f64")
+    a.step_many(1.0, 3)
+    f.step_many(1.0, 3)
+    share, all64 = a.force_precision_share()
+    print(f"   auto at dt 1.0: {share:.3f} ask, every wave float64: {all64}")
+    assert share > 0.5 and all64
+    assert np.array_equal(a.get_positions_f64(), f.get_positions_f64())
+    a.close(); f.close()
 
 
 def test_cluster_1m_direct_at_config_3_size(gpu, oracle):

@@ -462,3 +462,29 @@ def test_owner_mode_1m_bodies_eight_ranks_vs_single_handle_and_oracle(gpu, oracl
     assert sum(e.sim.n for e in engines) == n
     for e in engines:
         e.sim.close()
+
+
+def test_owner_mode_tree_export_repeats_when_its_launch_bound_was_too_small(gpu, monkeypatch):
+    """nbmi_owner_export_let sizes its launches from the previous step's node count and repeats with the exact count
+    when the header says the bound did not hold.  NBMI_LET_UNDERESTIMATE halves the bound, so every step from the
+    second on takes the repeat path: results must not change."""
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    from tools.presets import generate_distribution
+    np.random.seed(3)
+    n, world, steps, dt = 40_003, 2, 4, 0.05
+    pos, vel, mass = generate_distribution("galaxy", n, 500.0, 0.15)
+    G, eps, theta = 0.15, 3.0, 0.5
+
+    def run():
+        comm = _ThreadComm(world)
+        engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
+        steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+        out = _run_ranks(steppers, comm, dt, steps)
+        for e in engines:
+            e.sim.close()
+        return out[0][0]
+
+    ref = run()
+    monkeypatch.setenv("NBMI_LET_UNDERESTIMATE", "1")
+    got = run()
+    assert np.array_equal(got, ref)
