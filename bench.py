@@ -366,6 +366,36 @@ def bench_boids_slabs(args, n, dt, world, rank, dev):
             "exchange": {"rows_sent_last_step_rank0": int(eng.sent_rows), "row_bytes": 80}}
 
 
+def check_owner_mode(dist, world, rank, G, eps, theta, dt, n=262_144, steps=3, tol=1e-5):
+    """Owner mode ("let") against the replicated-tree mode ("rows", bit-identical to one GPU) on a small galaxy, over
+    the process group of this very run.  Every rank returns the same verdict (the error is all-reduced)."""
+    import torch
+    from nbody.sharded import create_sharded_simulation
+    from tools.presets import generate_distribution
+    res = {"ok": False, "bodies": n, "steps": steps, "tolerance": tol}
+    err = float("inf")
+    try:
+        np.random.seed(7)
+        p, v, m = generate_distribution("galaxy", n, 800.0, G)
+        rows = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode="rows")
+        rows.step(dt, steps)
+        rows.engine.sim.sync()
+        ref = rows.engine.sim.get_positions_f64()
+        rows.engine.sim.close()
+        let = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode="let")
+        let.step(dt, steps)
+        got, _ = let.gather_state()
+        let.engine.sim.close()
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    except Exception as ex:  # noqa: BLE001 - any failure of the untried mode means: use the tried one
+        res["error"] = repr(ex)[:300]
+    worst = torch.tensor([err if np.isfinite(err) else 1e30], dtype=torch.float64, device="cuda")
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    res["max_rel_position_diff"] = float(worst.item())
+    res["ok"] = bool(res["max_rel_position_diff"] <= tol)
+    return res
+
+
 def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu_budget_s=25.0):
     """One N-body workload: K timed steps (barrier + synchronize on both sides, max over ranks), then at
     N = 1 a second pass with per-phase HIP events, the counted walk, and the CPU port beside it."""
@@ -388,10 +418,18 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
     # N > 1, Barnes-Hut: "let" = owned key ranges + exchanged locally essential trees (BASELINE north_star's form,
     # per-rank cost does not grow with N); "rows" = replicated tree, bit-identical to one GPU (the exact mode)
     shard_mode = os.environ.get("NBMI_SHARD_MODE", "let")
+    mode_check = None
     with contextlib.redirect_stdout(sys.stderr):  # backend banners must not pollute the one JSON line
         if use_dist:
             import torch.distributed as dist
             from nbody.sharded import create_sharded_simulation
+            if method == "barnes_hut" and shard_mode == "let" and world > 1 and "NBMI_SHARD_MODE" not in os.environ:
+                # owner mode has never run over RCCL on >= 2 real GPUs.  Before anything is timed, the ranks
+                # of THIS run step a small system in both modes and compare: owner mode must stay within its stated
+                # tolerance of the bit-exact replicated-tree mode, or the timed run falls back to that mode.
+                mode_check = check_owner_mode(dist, world, rank, G, eps, theta, dt)
+                if not mode_check["ok"]:
+                    shard_mode = "rows"
             sharded = create_sharded_simulation(p, v, m, G, eps, 1.0, theta, mode=shard_mode, method=method)
             sim = sharded.engine.sim
             step = lambda k: sharded.step(dt, k)  # noqa: E731
@@ -450,6 +488,8 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
                    "parallelism": par},
     }
 
+    if mode_check is not None:
+        out["config"]["owner_mode_check"] = mode_check
     if use_dist and method == "barnes_hut" and shard_mode == "let" and rank == 0:
         e = sharded.engine
         out["exchange"] = {"bytes_sent_per_step_rank0": int(e.wire_bytes), "bodies_migrated_last_step_rank0": int(e.migrated),
