@@ -84,6 +84,7 @@ struct alignas(8) NodeD {
     unsigned next_off;  // index * 40
 };
 constexpr unsigned kNodeDBytes = 40;
+constexpr unsigned kBand64 = 2;  // half width (ulps of fp32 d^2) of the float64 loop's uncertainty band, see k_emit_tile
 static_assert(sizeof(NodeD) == kNodeDBytes, "NodeD must be 40 bytes");
 constexpr int64_t kMaxNodeDRows = 107000000;  // 32-bit byte offsets: 2^32 / 40
 // Node links are 32-bit byte offsets: at most 2^32 / 24 rows.  The reference allocates min(8 M, 4N)
@@ -781,7 +782,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             const int64_t nxt = e + pex_at(PexL, subPex, e);
             nd.next_off = (unsigned)nxt * kNodeBytes;
             nodes[idx] = nd;
-            if (nodesd) nodesd[idx] = NodeD{cx, cy, cz, M, nd.s2t, (unsigned)nxt * kNodeDBytes};
+            // [r3] the float64 loop tests a correctly rounded d^2: its uncertainty band is 2 ulps on either side of the
+            // threshold, not the K the fp32 loop needs for its rounded coordinates (re-decisions in float64 waves: 1 000 x fewer)
+            if (nodesd) nodesd[idx] = NodeD{cx, cy, cz, M, __int_as_float(__float_as_int(s2t) + (int)kBand64), (unsigned)nxt * kNodeDBytes};
             nodes64[idx] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
             if (diag64) diag64[idx] = make_double4(cx, cy, cz, M);
             if (node_ref) {
@@ -907,6 +910,10 @@ struct Body64 {
 // the reference's own test in float64 (simulation.py:249-258), operation for operation
 __device__ __forceinline__ bool exact_take_idx(unsigned idx, const Body64 &b) {
     const WalkTable *t = b.tab;
+    // (Measured and dropped [r3]: taking the centre of mass from the NodeD row and the half size from bounds / 2^level,
+    // so that Node64 need not be written - 0.1 ms less build at 10 M bodies, but the walk lost 0.5 ms: a wave leaves the
+    // loop for ~12 re-decisions per walk and each one waits for this function's dependent loads; one more level of them
+    // is 4 % of the walk.)
     const Node64 c = t->n64[idx];
     const Bodies &cur = t->buf[b.curbuf];
     const double dx = c.cx - cur.x[b.j], dy = c.cy - cur.y[b.j], dz = c.cz - cur.z[b.j];
@@ -1591,10 +1598,10 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
         unsigned off = 0u;
         while (off < nnd) {
             unsigned which = 0u;
-            walk4_asm64(nodesd, off, nnd, qx, qy, qz, eps2d, C.band2, resume, sx, sy, sz, which);
+            walk4_asm64(nodesd, off, nnd, qx, qy, qz, eps2d, 2u * kBand64, resume, sx, sy, sz, which);
             off = __builtin_amdgcn_readfirstlane(off);
             if (!__builtin_amdgcn_readfirstlane(which)) break;
-            off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, C.band2, C.b64, resume, sx, sy, sz);
+            off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, 2u * kBand64, C.b64, resume, sx, sy, sz);
         }
     } else if (!kCount && !kGuard) {
         if (nn && P.pair) {
@@ -1752,10 +1759,10 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
             unsigned res64 = resume == 0xffffffffu ? resume : resume / kNodeBytes * kNodeDBytes;
             while (off < end) {
                 unsigned which = 0u;
-                walk1_asm64(nodesd, off, end, qx, qy, qz, eps2d, C.band2, res64, sx, sy, sz, which);
+                walk1_asm64(nodesd, off, end, qx, qy, qz, eps2d, 2u * kBand64, res64, sx, sy, sz, which);
                 off = __builtin_amdgcn_readfirstlane(off);
                 if (!__builtin_amdgcn_readfirstlane(which)) break;
-                off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, C.band2, C.b64, res64, sx, sy, sz);
+                off = tie_visit64(nodesd, off, qx, qy, qz, eps2d, 2u * kBand64, C.b64, res64, sx, sy, sz);
             }
         }
     }

@@ -58,7 +58,19 @@ __global__ __launch_bounds__(kThreads) void k_radix_hist(const K *__restrict__ k
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
         const K k = keys[i];
-        for (int p = 0; p < passes; p++) atomicAdd(&h[p][digit_of(k, first_bit + p * kRadixBits)], 1u);
+        // [r3] The octree keys arrive nearly sorted (the state is kept in last step's key order), so the 64 keys of a
+        // wave share their upper digits: 64 LDS atomics on ONE counter, serialised (62 % of this kernel's wave cycles
+        // were LDS stalls).  A digit the whole wave agrees on is counted by one lane.
+        const unsigned live = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+        for (int p = 0; p < passes; p++) {
+            const unsigned d = digit_of(k, first_bit + p * kRadixBits);
+            const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__builtin_amdgcn_ballot_w64(d != d0) == 0ull) {
+                if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(&h[p][d0], live);
+            } else {
+                atomicAdd(&h[p][d], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < passes * kBins; i += kThreads) {

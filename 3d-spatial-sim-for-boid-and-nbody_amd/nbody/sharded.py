@@ -282,6 +282,16 @@ class LetBarnesHut:
         with scope:
             self._step(dt, substeps)
 
+    def _exchange_counts(self, send_counts, extras):
+        """recv_counts for this rank, the whole (source x destination) matrix and every rank's `extras` (its row budget
+        and the like) - via comm.counts_matrix when the communicator has it; a plain all-to-all of the counts otherwise."""
+        W = self.world
+        if hasattr(self.comm, "counts_matrix"):
+            row = np.concatenate([np.asarray(send_counts, dtype=np.int64), np.asarray(extras, dtype=np.int64)])
+            M = self.comm.counts_matrix(row)
+            return M[:, self.rank].copy(), M[:, :W], M[:, W:]
+        return self.comm.all_to_all_counts(send_counts), None, None
+
     def _step(self, dt, substeps):
         e, W = self.engine, self.world
         for _ in range(substeps):
@@ -301,7 +311,16 @@ class LetBarnesHut:
             send_counts = e.op_partition(allsamp)  # rows of the bodies that leave, grouped by destination
             n_recv = 0
             if W > 1:
-                recv_counts = self.comm.all_to_all_counts(send_counts)
+                held = e.sim.n if hasattr(e, "sim") else 0  # (a stand-in engine has no row budget: 0 rows of "infinity")
+                room = e.cap if hasattr(e, "sim") else (1 << 62)
+                recv_counts, M, ex = self._exchange_counts(send_counts, [held, room])
+                if M is not None:
+                    # every rank checks EVERY rank's body rows against THAT rank's budget and raises with it
+                    after = ex[:, 0] + M.sum(axis=0)  # rows a rank holds while it adopts: stayers, leavers' rows, arrivals
+                    if (after > ex[:, 1]).any():
+                        j = int(np.argmax(after - ex[:, 1]))
+                        raise RuntimeError(f"owner mode: rank {j} would hold {int(after[j])} body rows, capacity {int(ex[j, 1])} "
+                                           "(every rank raises this together; raise the head room in let_capacities)")
                 n_recv = int(recv_counts.sum())
                 self.comm.all_to_all_rows(e.recv_rows, e.send_rows, recv_counts, send_counts)
                 e.wait()
@@ -313,10 +332,16 @@ class LetBarnesHut:
                 self.comm.all_gather(e.boxes, e.bbox)
                 e.wait()
                 let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
-                counts = self.comm.all_to_all_counts(let_counts)
-                if int(counts.sum()) > e.let_recv.shape[0]:
-                    raise RuntimeError(f"rank {self.rank}: {int(counts.sum())} received tree rows exceed the "
-                                       f"{e.let_recv.shape[0]} reserved")
+                room = e.let_recv.shape[0]
+                counts, M, ex = self._exchange_counts(let_counts, [room])
+                if M is not None:  # the same verdict on every rank
+                    incoming = M.sum(axis=0)
+                    if (incoming > ex[:, 0]).any():
+                        j = int(np.argmax(incoming - ex[:, 0]))
+                        raise RuntimeError(f"owner mode: rank {j} would receive {int(incoming[j])} tree rows, {int(ex[j, 0])} "
+                                           "reserved (every rank raises this together)")
+                elif int(counts.sum()) > room:
+                    raise RuntimeError(f"rank {self.rank}: {int(counts.sum())} received tree rows exceed the {room} reserved")
                 self.comm.all_to_all_rows(e.let_recv, e.let_send, counts, let_counts)
                 e.wait()
                 wire += e.bbox.numel() * 8 + int(let_counts.sum()) * e.LET_ROW_BYTES
@@ -387,6 +412,16 @@ class DistComm:
         r = torch.empty_like(s)
         self.dist.all_to_all_single(r, s)
         return r.cpu().numpy()
+
+    def counts_matrix(self, send_row):
+        """(world, len(send_row)) int64: every rank's row, on every rank.  With the whole matrix each rank can make the
+        SAME decision about every other rank's buffers (a capacity error raised on one rank only leaves the
+        others waiting in the next collective until its time-out)."""
+        import torch
+        s = self._small(send_row)
+        r = torch.empty(self.dist.get_world_size() * s.numel(), dtype=torch.int64, device=s.device)
+        self.dist.all_gather_into_tensor(r, s)
+        return r.cpu().numpy().reshape(self.dist.get_world_size(), -1)
 
     def all_gather_counts(self, mine):
         import torch
