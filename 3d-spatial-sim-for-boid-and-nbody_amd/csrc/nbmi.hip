@@ -129,6 +129,10 @@ struct TreeInfo {
     // (k_flag_share; outside the ranges the per-step header reset clears)
     int force_all64;
     int pad1;
+    // owner mode [r3]: the own tree in its global form (k_chain_fix) - how many of its first nodes are copies of cells
+    // that begin on a lower rank (not walked, not exported), and where the walk array begins behind the jump node
+    int own_skip, own_added;
+    long long walk_first;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -618,11 +622,28 @@ __device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
 constexpr int kEmitTile = 2048;
 constexpr int kCellChunk = 4096;
 
-__device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t *__restrict__ node_ref, int64_t total) {
+// moments (G m, G m x, G m y, G m z summed) of the bodies at sorted ranks [r, e): in-tile prefix differences, plus
+// the double-double tile prefixes where the range crosses tiles
+__device__ __forceinline__ void range_moments(const double4 *__restrict__ S, const Moment *__restrict__ T, int64_t r, int64_t e,
+                                              double &M, double &mx, double &my, double &mz) {
+    const double4 s0 = S[r], s1 = S[e];
+    M = s1.x - s0.x; mx = s1.y - s0.y; my = s1.z - s0.z; mz = s1.w - s0.w;
+    const int64_t ur = r >> kSubShift, ue = e >> kSubShift;
+    if (ue != ur) {
+        const Moment a = T[ur], b = T[ue];
+        M += dd_diff(dd{b.m, b.ml}, dd{a.m, a.ml});
+        mx += dd_diff(dd{b.x, b.xl}, dd{a.x, a.xl});
+        my += dd_diff(dd{b.y, b.yl}, dd{a.y, a.yl});
+        mz += dd_diff(dd{b.z, b.zl}, dd{a.z, a.zl});
+    }
+}
+
+__device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t *__restrict__ node_ref, int64_t total,
+                                               int64_t link_base = 0) {
     Node sn;
     sn.cx = sn.cy = sn.cz = 1.0e30f;
     sn.gm = 0.f; sn.s2t = 0.f;
-    sn.next_off = (unsigned)total * kNodeBytes;
+    sn.next_off = (unsigned)(total + link_base) * kNodeBytes;
     nodes[total] = sn;
     if (node_ref) node_ref[total] = -1;
 }
@@ -636,7 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                                                       Node64 *__restrict__ nodes64, uint8_t *__restrict__ node_level,
                                                       int32_t *__restrict__ node_ref, double4 *__restrict__ diag64,
                                                       NodeD *__restrict__ nodesd /* may be null */, Bodies cur,
-                                                      const uint32_t *__restrict__ perm, double G, TreeInfo *info) {
+                                                      const uint32_t *__restrict__ perm, double G, TreeInfo *info,
+                                                      int64_t link_base /* owner mode: the arrays passed in begin at this row of
+                                                                           the walk array, and the links count from ITS start */) {
     __shared__ uint8_t tree[2 * kEmitTile];   // heap: tree[kEmitTile + i] = delta[base + i] + 1, inner nodes = min of children
     __shared__ uint8_t dprev;                 // delta[base - 1] + 1
     __shared__ uint32_t cells[kCellChunk];    // node slot -> (local body index << 6) | k (k-th node of that body)
@@ -654,8 +677,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                 info->sticky_nodes = total;
             }
         } else {
-            write_sentinel(nodes, node_ref, total);
-            if (nodesd) nodesd[total] = NodeD{1.0e30, 1.0e30, 1.0e30, 0.0, 0.0f, (unsigned)total * kNodeDBytes};
+            write_sentinel(nodes, node_ref, total, link_base);
+            if (nodesd) nodesd[total] = NodeD{1.0e30, 1.0e30, 1.0e30, 0.0, 0.0f, (unsigned)(total + link_base) * kNodeDBytes};
         }
     }
     if (total + 1 > capacity) return;
@@ -713,12 +736,12 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                 Node lf;
                 lf.cx = p.x; lf.cy = p.y; lf.cz = p.z; lf.gm = p.w;
                 lf.s2t = 0.0f;
-                lf.next_off = (unsigned)(idx + 1) * kNodeBytes;
+                lf.next_off = (unsigned)(idx + 1 + link_base) * kNodeBytes;
                 nodes[idx] = lf;
                 if (diag64) diag64[idx] = p64_s ? p64_s[r] : make_double4((double)p.x, (double)p.y, (double)p.z, (double)p.w);
                 if (nodesd) {  // the body as the float64 state has it (nearly sequential: the state is in last step's key order)
                     const uint32_t j = perm[r];
-                    nodesd[idx] = NodeD{cur.x[j], cur.y[j], cur.z[j], G * cur.m[j], 0.0f, (unsigned)(idx + 1) * kNodeDBytes};
+                    nodesd[idx] = NodeD{cur.x[j], cur.y[j], cur.z[j], G * cur.m[j], 0.0f, (unsigned)(idx + 1 + link_base) * kNodeDBytes};
                 }
                 if (node_ref) {  // queries and the owner-mode kernels only: a plain step does not pay for them
                     node_ref[idx] = (int32_t)r;
@@ -759,17 +782,8 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                 }
                 e = bad;
             }
-            // moments of [r, e)
-            const double4 s0 = S[r], s1 = S[e];
-            double M = s1.x - s0.x, mx = s1.y - s0.y, my = s1.z - s0.z, mz = s1.w - s0.w;
-            const int64_t ur = r >> kSubShift, ue = e >> kSubShift;
-            if (ue != ur) {
-                const Moment a = T[ur], b = T[ue];
-                M += dd_diff(dd{b.m, b.ml}, dd{a.m, a.ml});
-                mx += dd_diff(dd{b.x, b.xl}, dd{a.x, a.xl});
-                my += dd_diff(dd{b.y, b.yl}, dd{a.y, a.yl});
-                mz += dd_diff(dd{b.z, b.zl}, dd{a.z, a.zl});
-            }
+            double M, mx, my, mz;
+            range_moments(S, T, r, e, M, mx, my, mz);
             double cx = 0.0, cy = 0.0, cz = 0.0;
             if (M > 0.0) { cx = mx / M; cy = my / M; cz = mz / M; }
             const double size = ldexp(bounds, 1 - lev);  // 2 * bounds / 2^lev, exact
@@ -779,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             // upper edge of the uncertainty band: bits((2 hs)^2 / theta^2) + K  (theta == 0: +inf, never accepted)
             const float s2t = (float)(size * size * inv_theta2);
             nd.s2t = __int_as_float(__float_as_int(s2t) + (int)bandk);
-            const int64_t nxt = e + pex_at(PexL, subPex, e);
+            const int64_t nxt = e + pex_at(PexL, subPex, e) + link_base;
             nd.next_off = (unsigned)nxt * kNodeBytes;
             nodes[idx] = nd;
             // [r3] the float64 loop tests a correctly rounded d^2: its uncertainty band is 2 ulps on either side of the
@@ -898,6 +912,7 @@ struct WalkTable {
     const int32_t *pex, *subpex;  // leaf of the body at sorted rank r = node r + pex_at(pex, subpex, r + 1)
     unsigned long long *maxabs_next;  // TreeInfo::maxabs_next
     double theta, eps2;
+    long long own_base;  // owner mode: row of the walk array at which the handle's own tree begins (0 otherwise)
 };
 
 // where a lane finds its body's float64 position (only read on the re-decision path)
@@ -1609,13 +1624,14 @@ __global__ __launch_bounds__(kBlock) void k_walk(const Node *__restrict__ nodes,
             // Where to cut: a wave spends ~40 % of its visits inside the 1/64 of the array around its own bodies
             // (scripts/analysis/range_balance.py), so equal halves keep both cursors busy for only a fifth of the
             // visits; cutting at the leaf of the wave's middle body does for two thirds of them.
-            unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)(info_in->walk_nodes / 2) * kNodeBytes);
+            // (owner mode: the array begins with a jump node and unused rows up to walk_first)
+            unsigned mid = __builtin_amdgcn_readfirstlane((unsigned)((info_in->walk_first + info_in->walk_nodes) / 2) * kNodeBytes);
             if (P.pair == 2) {
                 const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
                 const int64_t r0 = P.rank_begin + (int64_t)lb * blockDim.x + wv * 64;
                 const int64_t rl = r0 + 64 < P.rank_end ? r0 + 64 : P.rank_end;  // the wave's bodies: [r0, rl)
                 const int64_t rm = r0 < rl ? r0 + (rl - r0) / 2 : 0;
-                const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + pex_at(tab->pex, tab->subpex, rm + 1)) * kNodeBytes);
+                const unsigned home = __builtin_amdgcn_readfirstlane((unsigned)(rm + pex_at(tab->pex, tab->subpex, rm + 1) + tab->own_base) * kNodeBytes);
                 mid = (r0 < rl && home > 0u && home < nn) ? home : mid;
             }
             // (each half sums into its own accumulator, added at the end: a body's result does not depend on how the two
@@ -1733,8 +1749,10 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     float ax = 0.f, ay = 0.f, az = 0.f;
     double sx = 0.0, sy = 0.0, sz = 0.0;  // two-level sums, see NBMI_FLUSH
     // wave-uniform range (w is the wave index): tell the compiler so
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * w / K) * kNodeBytes);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(num_nodes * (w + 1) / K) * kNodeBytes);
+    // (owner mode: rows [1, walk_first) behind the jump node at row 0 are unused; the parts divide the rest)
+    const int64_t first = frozen ? 0 : info_in->walk_first, span = num_nodes - first;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(w == 0 ? 0 : first + span * w / K) * kNodeBytes);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(first + span * (w + 1) / K) * kNodeBytes);
     // [r3] force precision of the group (all K waves of the workgroup walk the same 64 bodies): as in k_walk
     bool use64 = false;
     if (tab->nodesd && P.force_prec != 1)
@@ -2370,6 +2388,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_emigrants(Bodies cur, const uin
 // two distant corners of the system, and one such box keeps everything alive.)  The boxes come out in key
 // order (slot = exclusive scan of the emit flags over the pre-order array), so every kSuper consecutive ones
 // are neighbours in space and get a common "super box" for a two-level test.
+constexpr int kChainLevels = 43;  // cell levels 0 .. 42 (21 digits of the upper key word, 21 of the lower)
 constexpr int kBoxLevel = 4, kBoxLevelMax = 11;
 constexpr int kBoxesPerRank = 2048, kSuper = 32, kSupersPerRank = kBoxesPerRank / kSuper;
 constexpr int kMegasPerRank = 8, kSupersPerMega = kSupersPerRank / kMegasPerRank;
@@ -2378,7 +2397,8 @@ constexpr int kMegasPerRank = 8, kSupersPerMega = kSupersPerRank / kMegasPerRank
 __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ nodes, const uint8_t *__restrict__ node_level,
                                                       const int32_t *__restrict__ node_ref, const uint64_t *__restrict__ hi_s,
                                                       const uint64_t *__restrict__ lo_s, const TreeInfo *__restrict__ info,
-                                                      int64_t n, int64_t rows, int32_t *__restrict__ flag) {
+                                                      int64_t n, int64_t rows, int32_t *__restrict__ flag,
+                                                      int32_t *__restrict__ chainR, int64_t link_base) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= rows) return;  // the grid is rounded up to whole blocks: nothing behind the row budget is written
     const int64_t num_nodes = info->error ? 0 : info->num_nodes;
@@ -2388,11 +2408,15 @@ __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ n
     }
     const int l = node_level[i];
     int f = 0;
+    {   // [r3] the cells whose subtree ends with the array hold the rank's last body: one per level (k_chain_table)
+        const Node nd = nodes[i];
+        if (__float_as_int(nd.s2t) != 0 && (int64_t)(nd.next_off / kNodeBytes) - link_base == num_nodes && l < kChainLevels) chainR[l] = (int32_t)i;
+    }
     if (l <= kBoxLevelMax) {
         const Node nd = nodes[i];
         const bool leaf = __float_as_int(nd.s2t) == 0;
         const int64_t a = node_ref[i];
-        const int64_t nx = nd.next_off / kNodeBytes;
+        const int64_t nx = (int64_t)(nd.next_off / kNodeBytes) - link_base;
         const int64_t b = nx < num_nodes ? node_ref[nx] : n;
         const bool boundary = a == 0 || b == n;  // holds the rank's first or last body
         if (l < kBoxLevel) {
@@ -2412,13 +2436,13 @@ __global__ __launch_bounds__(kBlock) void k_box_flags(const Node *__restrict__ n
 __global__ __launch_bounds__(kBlock) void k_box_ranges(const Node *__restrict__ nodes, const int32_t *__restrict__ node_ref,
                                                        const int32_t *__restrict__ flag, const int32_t *__restrict__ slot,
                                                        const TreeInfo *__restrict__ info, int64_t rows, int64_t n,
-                                                       int32_t *__restrict__ ranges /* 2 x kBoxesPerRank */) {
+                                                       int32_t *__restrict__ ranges /* 2 x kBoxesPerRank */, int64_t link_base) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t num_nodes = info->error ? 0 : info->num_nodes;
     if (i >= num_nodes || !flag[i]) return;
     const int k = slot[i];
     if (k >= kBoxesPerRank) return;  // more cells than boxes: the last box takes everything from its cell on
-    const int64_t nx = nodes[i].next_off / kNodeBytes;
+    const int64_t nx = (int64_t)(nodes[i].next_off / kNodeBytes) - link_base;
     ranges[2 * k] = node_ref[i];
     ranges[2 * k + 1] = (k == kBoxesPerRank - 1 && slot[rows] > kBoxesPerRank) ? (int32_t)n
                                                                                     : (int32_t)(nx < num_nodes ? node_ref[nx] : n);
@@ -2562,6 +2586,209 @@ __global__ __launch_bounds__(kBlock) void k_iscan_apply(const int32_t *__restric
 }
 
 // ---- locally essential tree -----------------------------------------------------------------
+// [r3] One GLOBAL octree, cut into the ranks' pieces.  A rank's build (k_emit_tile) makes the octree of its own
+// bodies; the octree of ALL bodies differs from the ranks' trees side by side only along the rank boundaries:
+//   * cells that contain a rank's last body AND bodies of higher ranks: one cell in the global tree (first body on
+//     some rank A, the "owner"), a partial copy in every rank it reaches into;
+//   * cells that exist only because a rank's last body and the next rank's first body share more key digits than
+//     either shares with its neighbour on its own rank ("boundary-born" cells).
+// Round 2 walked the partial copies as they were - valid Barnes-Hut, but a DIFFERENT approximation than the
+// single-GPU tree: 2e-6 of the largest coordinate after 10 steps, 1.2e-4 after 50, 1.7e-3 after 100 at 1 M bodies
+// on 8 ranks, whatever the force precision (profiles/r03_owner_100_steps.jsonl).  Now every rank publishes a small
+// table about its two ends (ChainTable, all-gathered with the bounding boxes), and k_chain_fix turns the own tree
+// into the rank's piece of the global pre-order array:
+//   * the copies of cells that begin on a lower rank (always the FIRST own_skip nodes of the array) are dropped;
+//   * the cells along the path to the last body that reach into higher ranks get the global moments, the
+//     boundary-born ones are inserted in front of the last leaf (the last node of the array: nothing moves);
+//   * skip links that leave the rank name (rank, node) and are resolved where the pieces are put together.
+// Concatenated in rank order the pieces ARE the global pre-order array: every rank walks its own piece in full and a
+// pruned copy of the others', in rank order, i.e. the reference's accepted sets in the reference's order.
+constexpr unsigned kLinkTag = 0xFFFFFF00u;  // next_off >= this: a link that leaves the rank, slot = low byte (k_chain_fix)
+constexpr int kLinkEnd = 0xFE, kLinkLocal = 0xFF;
+struct ChainTable {
+    long long n;       // bodies of the rank (0: every other field is meaningless)
+    long long nodes;   // nodes of its tree as built (before k_chain_fix)
+    unsigned long long first_hi, first_lo, last_hi, last_lo;  // keys of its first / last body
+    long long d0, dR;  // common key digits of its first two / last two bodies (-1: a single body)
+    // level by level: how many of the rank's FIRST bodies share `level` digits with its first body (Lc), the node
+    // behind them in the rank's array (Ln; = nodes if all do) and their moments (Ls); the same from the end (Rc, Rs)
+    long long Lc[kChainLevels], Ln[kChainLevels], Rc[kChainLevels];
+    double Ls[kChainLevels][4], Rs[kChainLevels][4];
+};
+static_assert(sizeof(ChainTable) % 8 == 0, "ChainTable travels as doubles");
+constexpr int kChainDoubles = (int)(sizeof(ChainTable) / 8);
+
+__device__ __forceinline__ int chain_prev(const ChainTable *T, int x) {
+    for (int p = x - 1; p >= 0; p--) if (T[p].n > 0) return p;
+    return -1;
+}
+__device__ __forceinline__ int chain_next(const ChainTable *T, int W, int x) {
+    for (int z = x + 1; z < W; z++) if (T[z].n > 0) return z;
+    return -1;
+}
+// key digits the last body of rank x shares with the first body of rank y
+__device__ __forceinline__ int chain_cpl(const ChainTable *T, int x, int y) {
+    return cpl_digits(T[x].last_hi, T[x].last_lo, T[y].first_hi, T[y].first_lo);
+}
+// how many of rank x's first nodes are copies of cells that begin on a lower rank
+__device__ __forceinline__ int chain_skip(const ChainTable *T, int x) {
+    const int p = chain_prev(T, x);
+    if (p < 0) return 0;
+    const int db = chain_cpl(T, p, x), d0 = (int)T[x].d0;
+    return (db < d0 ? db : d0) + 1;
+}
+struct ChainCell {
+    double M, mx, my, mz;
+    int link_rank;        // rank on which the cell's subtree ends (kLinkEnd: with the last body of the last rank)
+    long long link_node;  // ... and the node (in that rank's numbering as built) that follows it
+};
+// The level-`lev` cell that holds the LAST body of rank x and reaches into the next rank.  The same function with
+// the same gathered tables on every rank that needs the cell (its owner for the record, the ranks it reaches into
+// for their pruning decisions): bit-identical moments everywhere.
+__device__ ChainCell chain_cell(const ChainTable *T, int W, int x, int lev) {
+    int a = x;  // the owner: leftwards while the whole rank lies inside the cell and the cell comes from further left
+    while (T[a].Rc[lev] == T[a].n) {
+        const int p = chain_prev(T, a);
+        if (p < 0 || chain_cpl(T, p, a) < lev) break;
+        a = p;
+    }
+    ChainCell c;
+    c.M = T[a].Rs[lev][0]; c.mx = T[a].Rs[lev][1]; c.my = T[a].Rs[lev][2]; c.mz = T[a].Rs[lev][3];
+    int y = a;
+    for (;;) {
+        const int z = chain_next(T, W, y);
+        if (z < 0) { c.link_rank = kLinkEnd; c.link_node = 0; break; }
+        if (chain_cpl(T, y, z) < lev) { c.link_rank = z; c.link_node = chain_skip(T, z); break; }
+        c.M += T[z].Ls[lev][0]; c.mx += T[z].Ls[lev][1]; c.my += T[z].Ls[lev][2]; c.mz += T[z].Ls[lev][3];
+        if (T[z].Lc[lev] < T[z].n) { c.link_rank = z; c.link_node = T[z].Ln[lev]; break; }
+        y = z;
+    }
+    return c;
+}
+// what follows a rank's last leaf in the global array: the first node the next rank keeps
+__device__ __forceinline__ void chain_after(const ChainTable *T, int W, int x, int &link_rank, long long &link_node) {
+    const int z = chain_next(T, W, x);
+    link_rank = z < 0 ? kLinkEnd : z;
+    link_node = z < 0 ? 0 : chain_skip(T, z);
+}
+
+// the rank's table (one wave, lane = level).  chainR[l] = node of the level-l cell that holds the last body
+// (k_box_flags notes them: the cells whose subtree ends with the array).
+__global__ void k_chain_table(const Node *__restrict__ nodes, const int32_t *__restrict__ node_ref, const int32_t *__restrict__ delta,
+                              const double4 *__restrict__ S, const Moment *__restrict__ T, const uint64_t *__restrict__ hi_s,
+                              const uint64_t *__restrict__ lo_s, int64_t n, const TreeInfo *__restrict__ info,
+                              const int32_t *__restrict__ chainR, int64_t link_base, ChainTable *__restrict__ out) {
+    const int lev = threadIdx.x;
+    const int64_t N = info->error ? 0 : info->num_nodes;
+    if (N == 0) n = 0;  // (a build that overflowed: the rank takes no part in this step's global tree; the error is sticky)
+    const int d0 = n >= 2 ? delta[0] : -1, dR = n >= 2 ? delta[n - 2] : -1;
+    if (lev == 0) {
+        out->n = n; out->nodes = N;
+        out->first_hi = n > 0 ? hi_s[0] : 0; out->first_lo = n > 0 ? lo_s[0] : 0;
+        out->last_hi = n > 0 ? hi_s[n - 1] : 0; out->last_lo = n > 0 ? lo_s[n - 1] : 0;
+        out->d0 = d0; out->dR = dR;
+    }
+    if (lev >= kChainLevels || n == 0) return;
+    int64_t Lc, Ln, Rc;
+    if (lev <= d0) {  // node `lev` is the level-lev cell of the first body (its cells are the first nodes of the array)
+        const int64_t nx = (int64_t)(nodes[lev].next_off / kNodeBytes) - link_base;
+        Lc = nx < N ? node_ref[nx] : n;
+        Ln = nx;
+    } else {
+        Lc = 1;
+        Ln = n >= 2 ? d0 + 2 : N;
+    }
+    if (lev <= dR) Rc = n - node_ref[chainR[lev]];
+    else Rc = 1;
+    out->Lc[lev] = Lc; out->Ln[lev] = Ln; out->Rc[lev] = Rc;
+    double M, mx, my, mz;
+    range_moments(S, T, 0, Lc, M, mx, my, mz);
+    out->Ls[lev][0] = M; out->Ls[lev][1] = mx; out->Ls[lev][2] = my; out->Ls[lev][3] = mz;
+    range_moments(S, T, n - Rc, n, M, mx, my, mz);
+    out->Rs[lev][0] = M; out->Rs[lev][1] = mx; out->Rs[lev][2] = my; out->Rs[lev][3] = mz;
+}
+
+struct OwnLink { int node; int rank; long long target; };  // node of the own array, (rank, node there) it links to
+constexpr int kOwnLinks = kChainLevels + 1;                  // a slot per level, one for the last leaf
+
+// The own tree becomes the rank's piece of the global array (see above).  One workgroup of 64, lane = level.
+__global__ void k_chain_fix(const ChainTable *__restrict__ T, int W, int me, Node *__restrict__ nodes, Node64 *__restrict__ n64,
+                            NodeD *__restrict__ nodesd, uint8_t *__restrict__ node_level, int32_t *__restrict__ node_ref,
+                            const int32_t *__restrict__ chainR, double inv_theta2, int64_t capacity, OwnLink *__restrict__ links,
+                            TreeInfo *info) {
+    const int lev = threadIdx.x;
+    const ChainTable &t = T[me];
+    const int64_t n = t.n, N = t.nodes;
+    if (lev < kOwnLinks) links[lev] = OwnLink{-1, 0, 0};
+    if (n == 0 || info->error) {
+        if (lev == 0) { info->own_skip = 0; info->own_added = 0; }
+        return;
+    }
+    const int p = chain_prev(T, me), z = chain_next(T, W, me);
+    const int dprev = p >= 0 ? chain_cpl(T, p, me) : -1, dnext = z >= 0 ? chain_cpl(T, me, z) : -1;
+    const int dR = (int)t.dR;
+    const int lo_new = n == 1 ? (dprev > dR ? dprev : dR) : dR;  // levels above this one and up to dnext are boundary-born
+    const int c = dnext > lo_new ? dnext - lo_new : 0;
+    if (N + c + 1 > capacity) {
+        if (lev == 0) {
+            info->error = 1;
+            if (info->sticky_error == 0) { info->sticky_error = 1; info->sticky_nodes = N + c; }
+        }
+        return;
+    }
+    // the last leaf first (the new cells take its place)
+    const Node leaf = nodes[N - 1];
+    const uint8_t leaf_level = node_level[N - 1];
+    NodeD leafd = NodeD{0.0, 0.0, 0.0, 0.0, 0.0f, 0u};
+    if (nodesd) leafd = nodesd[N - 1];
+    __syncthreads();
+    const bool exists = lev < kChainLevels && lev <= dR, born = lev < kChainLevels && lev > lo_new && lev <= dnext;
+    if (exists || born) {
+        const int64_t i = exists ? chainR[lev] : (N - 1) + (lev - lo_new - 1);
+        const bool from_left = t.Rc[lev] == n && dprev >= lev;  // begins on a lower rank: that rank's to describe
+        if (!from_left) {
+            int lr; long long ln;
+            if (lev <= dnext) {
+                const ChainCell cc = chain_cell(T, W, me, lev);
+                lr = cc.link_rank; ln = cc.link_node;
+                double cx = 0.0, cy = 0.0, cz = 0.0;
+                if (cc.M > 0.0) { cx = cc.mx / cc.M; cy = cc.my / cc.M; cz = cc.mz / cc.M; }
+                const double bounds = info->bounds;
+                const double size = ldexp(bounds, 1 - lev);
+                const float s2t = (float)(size * size * inv_theta2);
+                Node nd;
+                nd.cx = (float)cx; nd.cy = (float)cy; nd.cz = (float)cz; nd.gm = (float)cc.M;
+                nd.s2t = __int_as_float(__float_as_int(s2t) + (int)(info->band2 >> 1));
+                nd.next_off = kLinkTag | (unsigned)lev;
+                nodes[i] = nd;
+                n64[i] = Node64{cx, cy, cz, ldexp(bounds, -lev)};
+                if (nodesd) nodesd[i] = NodeD{cx, cy, cz, cc.M, __int_as_float(__float_as_int(s2t) + (int)kBand64), kLinkTag | (unsigned)lev};
+                if (born) { node_level[i] = (uint8_t)lev; node_ref[i] = (int32_t)(n - 1); }
+            } else {  // ends with the rank's last body: only its skip link leaves the rank
+                chain_after(T, W, me, lr, ln);
+                nodes[i].next_off = kLinkTag | (unsigned)lev;
+                if (nodesd) nodesd[i].next_off = kLinkTag | (unsigned)lev;
+            }
+            links[lev] = OwnLink{(int)i, lr, ln};
+        }
+    }
+    if (lev == kChainLevels) {  // the last leaf, behind the boundary-born cells
+        const int64_t i = N - 1 + c;
+        Node lf = leaf;
+        lf.next_off = kLinkTag | (unsigned)kChainLevels;
+        nodes[i] = lf;
+        if (nodesd) { leafd.next_off = kLinkTag | (unsigned)kChainLevels; nodesd[i] = leafd; }
+        node_ref[i] = (int32_t)(n - 1);
+        node_level[i] = leaf_level + (uint8_t)c;
+        int lr; long long ln;
+        chain_after(T, W, me, lr, ln);
+        links[kChainLevels] = OwnLink{(int)i, lr, ln};
+        info->num_nodes = N + c;
+        info->own_skip = chain_skip(T, me);
+        info->own_added = c;
+    }
+}
+
 // A cell can only be opened by a body of another rank if the opening test can fail somewhere in one of that
 // rank's bounding boxes; if it cannot (for any other rank), nobody else ever looks below it and its subtree
 // stays home.  Conservative by a 1e-9 margin on both sides of the float64 test.  diff[] marks the dropped
@@ -2574,43 +2801,78 @@ __device__ __forceinline__ bool box_may_open(const double *__restrict__ b, const
     const double dz = fmax(0.0, fmax(b[2] - c.cz, c.cz - b[5]));
     return (dx * dx + dy * dy + dz * dz + eps2) * (1.0 - 1e-9) <= thr;  // some point of the box may fail "size / dist < theta"
 }
+// may a body of rank j open the cell?  Four-level test: the union box of the rank, its mega boxes, super boxes, boxes.
+__device__ __forceinline__ bool rank_may_open(int j, const Node64 &c, double eps2, double thr, const double *__restrict__ boxes,
+                                              const double *__restrict__ supers, const double *__restrict__ megas,
+                                              const double *__restrict__ rankbox) {
+    if (!box_may_open(rankbox + 6 * j, c, eps2, thr)) return false;
+    for (int g = j * kMegasPerRank; g < (j + 1) * kMegasPerRank; g++) {
+        if (!box_may_open(megas + 6 * g, c, eps2, thr)) continue;
+        for (int sb = g * kSupersPerMega; sb < (g + 1) * kSupersPerMega; sb++) {
+            if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
+            for (int k = 0; k < kSuper; k++)
+                if (box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr)) return true;
+        }
+    }
+    return false;
+}
 // one pass over the own tree decides for EVERY destination rank: diff row j marks the pre-order ranges rank j
-// does not need.  Four-level test per destination: the union box of the rank, its mega boxes, super boxes, boxes.
+// does not need.
 __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
                                                      int64_t num_nodes, const double *__restrict__ boxes,
                                                      const double *__restrict__ supers, const double *__restrict__ megas,
                                                      const double *__restrict__ rankbox, int world, int me, double theta, double eps2,
-                                                     int32_t *__restrict__ diff, int64_t stride, const TreeInfo *__restrict__ info) {
+                                                     int32_t *__restrict__ diff, int64_t stride, const TreeInfo *__restrict__ info,
+                                                     int64_t link_base) {
     // (a wave-uniform form of these loops - a level entered if ANY lane needs it, box data by scalar loads -
     // was slower, 266 vs 190 us at 8 ranks: the lanes' early exits are worth more than the cheaper loads)
     // `num_nodes` is the host's launch bound (it may be an estimate from the previous step); the tree's own count is
     // on the device
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= num_nodes || i >= info->num_nodes) return;
+    const int64_t N = info->num_nodes;
+    if (i >= num_nodes || i >= N || i < info->own_skip) return;  // (the first own_skip nodes: k_let_mark_left speaks for them)
     const Node nd = nodes[i];
     if (__float_as_int(nd.s2t) == 0) return;  // a leaf: nothing below it
     const Node64 c = n64[i];
     const double size = c.hs * 2.0;
     const bool all = !(theta > 0.0);  // theta == 0: every cell is opened by everybody
     const double thr = all ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
-    const int64_t nx = nd.next_off / kNodeBytes;
+    const int64_t nx = nd.next_off >= kLinkTag ? N : (int64_t)(nd.next_off / kNodeBytes) - link_base;  // (a subtree that leaves the rank: to the end of the array)
     if (nx <= i + 1) return;
     for (int j = 0; j < world; j++) {
         if (j == me) continue;
-        bool needed = all;
-        if (!needed && box_may_open(rankbox + 6 * j, c, eps2, thr)) {
-            for (int g = j * kMegasPerRank; g < (j + 1) * kMegasPerRank && !needed; g++) {
-                if (!box_may_open(megas + 6 * g, c, eps2, thr)) continue;
-                for (int sb = g * kSupersPerMega; sb < (g + 1) * kSupersPerMega && !needed; sb++) {
-                    if (!box_may_open(supers + 6 * sb, c, eps2, thr)) continue;
-                    for (int k = 0; k < kSuper && !needed; k++) needed = box_may_open(boxes + 6 * ((int64_t)sb * kSuper + k), c, eps2, thr);
-                }
-            }
-        }
-        if (!needed) {
+        if (!all && !rank_may_open(j, c, eps2, thr, boxes, supers, megas, rankbox)) {
             int32_t *d = diff + (int64_t)j * stride;
             atomicAdd(&d[i + 1], 1);
             atomicAdd(&d[nx], -1);
+        }
+    }
+}
+// The cells that begin on a lower rank and reach into this one: their owner decides with the global moments whether
+// a destination needs their subtree; this rank takes the same decision from the same numbers (chain_cell) for the
+// part of the subtree that lies in ITS array: nodes [0, Ln[level]).  One wave, lane = level.
+__global__ void k_let_mark_left(const ChainTable *__restrict__ T, int world, int me, const double *__restrict__ boxes,
+                                const double *__restrict__ supers, const double *__restrict__ megas,
+                                const double *__restrict__ rankbox, double theta, double eps2, int32_t *__restrict__ diff,
+                                int64_t stride, const TreeInfo *__restrict__ info) {
+    const int lev = threadIdx.x;
+    const ChainTable &t = T[me];
+    if (lev >= kChainLevels || t.n == 0 || info->error) return;
+    const int p = chain_prev(T, me);
+    if (p < 0 || chain_cpl(T, p, me) < lev) return;
+    if (!(theta > 0.0)) return;  // everybody opens everything
+    const ChainCell cc = chain_cell(T, world, p, lev);
+    Node64 c{0.0, 0.0, 0.0, ldexp(info->bounds, -lev)};
+    if (cc.M > 0.0) { c.cx = cc.mx / cc.M; c.cy = cc.my / cc.M; c.cz = cc.mz / cc.M; }
+    const double size = c.hs * 2.0;
+    const double thr = (size / theta) * (size / theta) * (1.0 + 1e-9);
+    const int64_t end = t.Lc[lev] < t.n ? t.Ln[lev] : info->num_nodes;
+    for (int j = 0; j < world; j++) {
+        if (j == me) continue;
+        if (!rank_may_open(j, c, eps2, thr, boxes, supers, megas, rankbox)) {
+            int32_t *d = diff + (int64_t)j * stride;
+            atomicAdd(&d[0], 1);
+            atomicAdd(&d[end], -1);
         }
     }
 }
@@ -2619,17 +2881,34 @@ __global__ __launch_bounds__(kBlock) void k_let_keep(const int32_t *__restrict__
                                                      const TreeInfo *__restrict__ info) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t o = (int64_t)blockIdx.y * stride;
-    if (i < num_nodes) keep[o + i] = (i < info->num_nodes && (diff_ex[o + i] + diff[o + i]) == 0) ? 1 : 0;
+    if (i < num_nodes) keep[o + i] = (i >= info->own_skip && i < info->num_nodes && (diff_ex[o + i] + diff[o + i]) == 0) ? 1 : 0;
 }
 // kept nodes move to their new index in the destination's segment; links are re-based to the compacted
-// numbering (a kept node's successor is always kept: it hangs off one of the node's own ancestors).  A row of
-// the exchange buffer is 56 bytes: the 24-byte walk record, then its float64 twin.
-constexpr int kLetRow = 56;
+// numbering (a kept node's successor is always kept: it hangs off one of the node's own ancestors - on whichever
+// rank that is: all ranks decide about a cell from the same numbers).  A row of the exchange buffer is 48 bytes,
+// everything in float64 (LetRow): the receiver rounds the fp32 walk record out of it exactly as the sender's build
+// did, and rebuilds the float64 record of the float64 force loop from the same numbers ([r3]; round 2 shipped the
+// 24-byte fp32 record + a 32-byte float64 twin and owner mode had fp32 forces only).
+struct LetRow {
+    double cx, cy, cz, gm;  // centre of mass / body position, G * mass
+    float s2t;              // as in Node (the fp32 loop's band included; 0: a leaf)
+    unsigned next;          // skip link: node index in the compacted segment (link_rank = kLinkLocal), or the node of
+                            // rank link_rank (in that rank's numbering behind ITS dropped copies) that follows the subtree
+    unsigned orig;          // the node's index in the sender's array, behind the sender's dropped copies
+    uint8_t level;          // cell level (half size = root half size / 2^level)
+    uint8_t link_rank;
+    uint16_t pad;
+};
+static_assert(sizeof(LetRow) == 48, "LetRow is a 48-byte wire row");
+constexpr int kLetRow = 48;
 __global__ __launch_bounds__(kBlock) void k_let_compact(const Node *__restrict__ nodes, const Node64 *__restrict__ n64,
+                                                        const NodeD *__restrict__ nodesd /* may be null */,
+                                                        const uint8_t *__restrict__ node_level, const OwnLink *__restrict__ links,
+                                                        const ChainTable *__restrict__ T,
                                                         const int32_t *__restrict__ keep, const int32_t *__restrict__ newidx,
                                                         int64_t num_nodes, int64_t stride, int64_t capacity, int me,
                                                         const int64_t *__restrict__ seg_off, char *__restrict__ out,
-                                                        const TreeInfo *__restrict__ info) {
+                                                        const TreeInfo *__restrict__ info, int64_t link_base) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int j = blockIdx.y;
     if (j == me || i >= num_nodes || i >= info->num_nodes) return;
@@ -2637,14 +2916,31 @@ __global__ __launch_bounds__(kBlock) void k_let_compact(const Node *__restrict__
     if (!keep[o + i]) return;
     const int64_t k = seg_off[j] + newidx[o + i];
     if (k >= capacity) return;  // reported through the counts
-    Node nd = nodes[i];
-    const int64_t nx = nd.next_off / kNodeBytes;
-    nd.next_off = (unsigned)newidx[o + nx] * kNodeBytes;
-    char *row = out + k * kLetRow;
-    *reinterpret_cast<Node *>(row) = nd;
-    const Node64 c = n64[i];
-    double *d = reinterpret_cast<double *>(row + kNodeBytes);
-    d[0] = c.cx; d[1] = c.cy; d[2] = c.cz; d[3] = c.hs;
+    const Node nd = nodes[i];
+    const bool leaf = __float_as_int(nd.s2t) == 0;
+    LetRow row;
+    row.s2t = nd.s2t;
+    row.orig = (unsigned)(i - info->own_skip);
+    row.level = node_level[i];
+    row.pad = 0;
+    if (nd.next_off >= kLinkTag) {
+        const OwnLink L = links[nd.next_off & 0xffu];
+        row.link_rank = (uint8_t)L.rank;
+        row.next = L.rank == kLinkEnd ? 0u : (unsigned)(L.target - chain_skip(T, L.rank));
+    } else {
+        row.link_rank = (uint8_t)kLinkLocal;
+        row.next = (unsigned)newidx[o + (int64_t)(nd.next_off / kNodeBytes) - link_base];
+    }
+    if (nodesd) {  // the float64 record has the unrounded numbers of leaves and cells alike
+        const NodeD d = nodesd[i];
+        row.cx = d.cx; row.cy = d.cy; row.cz = d.cz; row.gm = d.gm;
+    } else if (!leaf) {
+        const Node64 c = n64[i];
+        row.cx = c.cx; row.cy = c.cy; row.cz = c.cz; row.gm = (double)nd.gm;
+    } else {  // an fp32-only handle keeps no float64 copy of a leaf
+        row.cx = (double)nd.cx; row.cy = (double)nd.cy; row.cz = (double)nd.cz; row.gm = (double)nd.gm;
+    }
+    *reinterpret_cast<LetRow *>(out + k * kLetRow) = row;
 }
 // rows per destination and where each destination's segment starts in the (packed) send buffer
 __global__ void k_let_counts(const int32_t *__restrict__ newidx, int64_t num_nodes, int64_t stride, int world, int me,
@@ -2680,30 +2976,86 @@ __global__ __launch_bounds__(kMaxWorld * kMegasPerRank) void k_rank_boxes(const 
         for (int c = 0; c < 6; c++) rankbox[6 * j + c] = v[c];
     }
 }
-// a received tree goes behind the trees already in the walk array: links shift by the base
-__global__ __launch_bounds__(kBlock) void k_let_append(const char *__restrict__ src, int64_t count, int64_t base,
-                                                       Node *__restrict__ nodes, Node64 *__restrict__ n64) {
-    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (k >= count) return;
-    const char *row = src + k * kLetRow;
-    Node nd = *reinterpret_cast<const Node *>(row);
-    nd.next_off += (unsigned)base * kNodeBytes;
-    nodes[base + k] = nd;
-    const double *d = reinterpret_cast<const double *>(row + kNodeBytes);
-    n64[base + k] = Node64{d[0], d[1], d[2], d[3]};
-}
-// total < 0: nothing was received, the walk array is the own tree as built (its sentinel is in place)
-__global__ void k_let_finish(Node *__restrict__ nodes, int64_t total, TreeInfo *info) {
-    if (total < 0) {
-        info->walk_nodes = info->num_nodes;
-        return;
+// Where the pieces lie in a rank's walk array, in rank order:
+//   row 0: a jump node (a massless leaf everybody accepts, its skip link leads to walk_first)
+//   [walk_first, own_base + own_skip): the received pieces of the lower ranks, packed up against
+//   [own_base + own_skip, own_base + num_nodes): the own piece, where k_emit_tile / k_chain_fix built it
+//   behind it the received pieces of the higher ranks, then the sentinel.
+struct Pieces {
+    const char *src[kMaxWorld];  // received rows of each rank (null: none / the own rank)
+    long long count[kMaxWorld];
+    long long base[kMaxWorld];   // first row of the rank's piece in the walk array (own rank: own_base + own_skip)
+    long long total;             // row of the sentinel
+    int me;
+};
+// a link (rank, node behind that rank's dropped copies) -> row of the walk array.  The rows of a received piece are
+// in pre-order, so the first row at or behind the node is looked up.  A link whose target was pruned belongs to a
+// node nobody here can reach (a cell above both of them is never opened - deep cells below theta * softening are
+// opened by nobody, not even by the bodies inside them); it then leads to the next node that IS here, which is
+// where a walk leaves that never-entered subtree anyway.  The pieces follow each other without gaps in rank order,
+// so "behind the last row of a piece" is the first row of the next.
+__device__ __forceinline__ long long piece_row(const Pieces &P, int rank, long long node) {
+    if (rank == kLinkEnd) return P.total;
+    if (rank == P.me) return P.base[rank] + node;
+    long long lo = 0, hi = P.count[rank];
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        const unsigned o = reinterpret_cast<const LetRow *>(P.src[rank] + mid * kLetRow)->orig;
+        if (o < (unsigned)node) lo = mid + 1; else hi = mid;
     }
-    Node sn;
-    sn.cx = sn.cy = sn.cz = 1.0e30f;
-    sn.gm = 0.f; sn.s2t = 0.f;
-    sn.next_off = (unsigned)total * kNodeBytes;
-    nodes[total] = sn;
-    info->walk_nodes = total;
+    return P.base[rank] + lo;
+}
+__global__ __launch_bounds__(kBlock) void k_let_append(Pieces P, int from, Node *__restrict__ nodes, Node64 *__restrict__ n64,
+                                                       NodeD *__restrict__ nodesd /* may be null */, TreeInfo *info) {
+    const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= P.count[from]) return;
+    const LetRow row = *reinterpret_cast<const LetRow *>(P.src[from] + k * kLetRow);
+    const long long base = P.base[from];
+    const long long nx = row.link_rank == kLinkLocal ? base + row.next : piece_row(P, row.link_rank, row.next);
+    const bool leaf = __float_as_int(row.s2t) == 0;
+    Node nd;
+    nd.cx = (float)row.cx; nd.cy = (float)row.cy; nd.cz = (float)row.cz; nd.gm = (float)row.gm;
+    nd.s2t = row.s2t;
+    nd.next_off = (unsigned)nx * kNodeBytes;
+    nodes[base + k] = nd;
+    n64[base + k] = Node64{row.cx, row.cy, row.cz, leaf ? 0.0 : ldexp(info->bounds, -(int)row.level)};
+    if (nodesd) {
+        // the float64 loop's narrow band instead of the fp32 loop's (every rank derives the same band from the
+        // global extent, k_emit_tile)
+        const int bits = __float_as_int(row.s2t);
+        const float s2d = bits == 0 ? 0.0f : __int_as_float(bits - (int)(info->band2 >> 1) + (int)kBand64);
+        nodesd[base + k] = NodeD{row.cx, row.cy, row.cz, row.gm, s2d, (unsigned)nx * kNodeDBytes};
+    }
+}
+// the own piece's links that leave the rank, the jump node, the sentinel (one wave)
+__global__ void k_let_finish(Pieces P, const OwnLink *__restrict__ links, const ChainTable *__restrict__ T, long long own_base,
+                             long long walk_first, Node *__restrict__ nodes, NodeD *__restrict__ nodesd, TreeInfo *info) {
+    const int t = threadIdx.x;
+    if (t < kOwnLinks && links[t].node >= 0) {
+        const int lr = links[t].rank;
+        const long long nx = piece_row(P, lr, lr == kLinkEnd ? 0 : links[t].target - chain_skip(T, lr));
+        const long long i = own_base + links[t].node;
+        nodes[i].next_off = (unsigned)nx * kNodeBytes;
+        if (nodesd) nodesd[i].next_off = (unsigned)nx * kNodeDBytes;
+    }
+    if (t == 0) {
+        Node sn;
+        sn.cx = sn.cy = sn.cz = 1.0e30f;
+        sn.gm = 0.f; sn.s2t = 0.f;
+        sn.next_off = (unsigned)P.total * kNodeBytes;
+        nodes[P.total] = sn;
+        if (nodesd) nodesd[P.total] = NodeD{1.0e30, 1.0e30, 1.0e30, 0.0, 0.0f, (unsigned)P.total * kNodeDBytes};
+        sn.next_off = (unsigned)walk_first * kNodeBytes;  // the jump node: accepted by every lane, adds nothing
+        nodes[0] = sn;
+        if (nodesd) nodesd[0] = NodeD{1.0e30, 1.0e30, 1.0e30, 0.0, 0.0f, (unsigned)walk_first * kNodeDBytes};
+        info->walk_nodes = P.total;
+        info->walk_first = walk_first;
+    }
+}
+// world 1: nothing was received, the walk array is the own tree as built (its sentinel is in place)
+__global__ void k_let_finish_alone(TreeInfo *info) {
+    info->walk_nodes = info->num_nodes;
+    info->walk_first = 0;
 }
 __global__ void k_copy_ids(const int32_t *__restrict__ ids, int32_t *__restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2781,6 +3133,10 @@ struct nbmi_sim {
     TreeInfo *h_info = nullptr;   // pinned host copy of the tree header, refreshed by every nbmi_owner_adopt
     hipEvent_t ev_info = nullptr;  // ... complete when this event is
     int64_t last_nodes = -1;      // num_nodes of the previous step's own tree (launch bound of this step's tree export)
+    int64_t own_base = 0;         // [r3] row of the walk array at which the own tree is built (world > 1: behind the room for the lower ranks' pieces)
+    int32_t *chain_r = nullptr;   // nodes of the cells that hold the rank's last body, by level
+    OwnLink *own_links = nullptr; // the own piece's links that leave the rank
+    const ChainTable *chains = nullptr;  // every rank's table (the caller's gathered buffer of this step)
     // frame codec: previous decoded frame (positions then colours, float32, caller's order) and the int16 payload
     float *frame_prev = nullptr;
     int16_t *frame_q = nullptr;
@@ -2795,6 +3151,7 @@ struct nbmi_sim {
     unsigned char *wave_flag = nullptr;  // device [one per wave]
     int32_t *sub_flag = nullptr;         // device [one per tile]: waves of the tile that ask for float64
     double step_dt = 0.0;                // dt of the step being enqueued (0: a build without a step)
+    double owner_dt = 0.0;               // owner mode: the dt the next nbmi_owner_step will use (nbmi_owner_set_dt; "auto" needs it at build time)
     int balance_blocks = 0;           // the block count the bounds on the device were made for (0: none yet)
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
@@ -2853,6 +3210,7 @@ int upload_walk_table(nbmi_sim *s) {
     t.maxabs_next = &s->info->maxabs_next;
     t.theta = s->theta;
     t.eps2 = s->softening * s->softening;
+    t.own_base = s->own_base;
     NBMI_HIP_CHECK(hipMemcpyAsync(s->wtab, &t, sizeof(t), hipMemcpyHostToDevice, s->stream));
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));  // `t` is a stack object
     return 0;
@@ -2948,10 +3306,11 @@ int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
                                                    auto_prec(s) ? s->sub_flag : nullptr, (n + 63) / 64, s->info);
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
+    const int64_t ob = s->own_base;  // (owner mode: the own tree begins at this row of the walk array; node_level / node_ref / diag64 count from the tree's start)
     k_emit_tile<<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
         s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
-        inv_theta2, s->nodes, s->nodes64, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
-        s->force_prec != 1 ? s->nodesd : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info);
+        inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
+        s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob);
     if (s->walk_stack)
         k_child_table<<<nblocks(s->own_node_rows), kBlock, 0, st>>>(s->nodes, s->info, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
@@ -2991,6 +3350,7 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
     if (cntr <= 0) return 0;
     P.xcd_chunk = s->xcd_chunk;
     P.pair = s->walk_pair >= 0 ? s->walk_pair : (s->nt >= kHomeSplitBodies ? 2 : 1);
+    if (s->owner && s->world > 1 && P.pair == 1) P.pair = 2;  // (the middle of the array may lie in the unused rows in front of the pieces)
     P.curbuf = s->curbuf;
     P.acc64 = getenv("NBMI_ACC64") ? atoi(getenv("NBMI_ACC64")) : 0;
     P.balance = 0;
@@ -3220,7 +3580,7 @@ static int create_impl(nbmi_sim *s, const double *pos, const double *vel, const 
             (s->prec && dev_alloc(s, &s->diag64, own_rows)) ||
             dev_alloc(s, &s->xcd_bounds, 16) || dev_alloc(s, &s->wave_cycles, (size_t)4 * ((c + 63) / 64 + 8)) ||
             dev_alloc(s, &s->wave_flag, (size_t)(c + 63) / 64 + 64) || dev_alloc(s, &s->sub_flag, (c + 1) / kScanTile + 2) ||
-            (s->force_prec != 1 && !s->owner && s->softening > 1e-12 && s->node_capacity + 2 <= kMaxNodeDRows &&
+            (s->force_prec != 1 && s->softening > 1e-12 && s->node_capacity + 2 <= kMaxNodeDRows &&
              dev_alloc(s, &s->nodesd, s->node_capacity + 2)) ||
             false)
             return -2;
@@ -3724,7 +4084,10 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
     s->G = G; s->softening = softening; s->damping = damping; s->theta = theta;
     s->owner = true; s->world = world; s->rank = rank;
     s->let_capacity = let_capacity;
-    s->node_extra = world > 1 ? let_capacity : 0;
+    // the own tree sits in the MIDDLE of the walk array: room for received pieces in front of it (lower ranks) and
+    // behind it (higher ranks), a jump node at row 0
+    s->node_extra = world > 1 ? 2 * let_capacity + 2 : 0;
+    s->own_base = world > 1 ? let_capacity + 1 : 0;
     read_env_knobs(s);
     int rc = create_impl(s, pos, vel, mass);
     if (rc == 0) {
@@ -3738,7 +4101,8 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *pos, const double *vel, con
             dev_alloc(s, &s->let_diff, all) || dev_alloc(s, &s->let_scan, all) || dev_alloc(s, &s->let_keep, all) ||
             dev_alloc(s, &s->let_tiles, (size_t)s->let_tile_stride * world) || dev_alloc(s, &s->let_ranges, 2 * kBoxesPerRank) ||
             dev_alloc(s, &s->let_supers, (size_t)6 * kSupersPerRank * kMaxWorld) ||
-            dev_alloc(s, &s->let_megas, (size_t)6 * kMegasPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld))
+            dev_alloc(s, &s->let_megas, (size_t)6 * kMegasPerRank * kMaxWorld) || dev_alloc(s, &s->let_rankbox, 6 * kMaxWorld) ||
+            dev_alloc(s, &s->chain_r, kChainLevels) || dev_alloc(s, &s->own_links, kOwnLinks))
             rc = -2;
         if (rc == 0 && (hipHostMalloc((void **)&s->h_info, sizeof(TreeInfo)) != hipSuccess || hipEventCreate(&s->ev_info) != hipSuccess ||
                         hipMemsetAsync(s->let_dead, 0, (size_t)c, s->stream) != hipSuccess)) {
@@ -3837,7 +4201,10 @@ int nbmi_owner_partition(nbmi_sim *s, const void *dev_all_samples, int total_sam
     return 0;
 }
 
-int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes) {
+int nbmi_owner_chain_doubles(void) { return kChainDoubles; }
+
+int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes,
+                     void *dev_chain) {
     if (int rc = owner_check(s, "nbmi_owner_adopt")) return rc;
     const int64_t n_old = s->n, n_work = n_old + n_recv, n_new = n_old - s->n_leaving + n_recv;
     if (n_recv < 0 || n_work > s->cap) {
@@ -3845,7 +4212,10 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
                         (long long)n_old, (long long)n_recv, (long long)s->cap);
         return NBMI_ERR_CAPACITY;
     }
-    if ((n_recv > 0 && !dev_recv_rows) || !dev_maxabs || !dev_boxes) { nbmi::set_error("nbmi_owner_adopt: null buffer"); return NBMI_ERR_ARG; }
+    if ((n_recv > 0 && !dev_recv_rows) || !dev_maxabs || !dev_boxes || (s->world > 1 && !dev_chain)) {
+        nbmi::set_error("nbmi_owner_adopt: null buffer");
+        return NBMI_ERR_ARG;
+    }
     hipStream_t st = s->stream;
     Bodies cur = s->buf[s->curbuf];
     // immigrants go behind the rows already here; the emigrants' rows stay in place, flagged dead
@@ -3858,6 +4228,8 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
     // the tree header of this step: cleared, then the GLOBAL extent (every rank builds inside the same root cube)
     NBMI_HIP_CHECK(hipMemsetAsync(s->info, 0, offsetof(TreeInfo, wave_visits), st));
     NBMI_HIP_CHECK(hipMemcpyAsync(&s->info->maxabs_bits, dev_maxabs, 8, hipMemcpyDeviceToDevice, st));
+    s->step_dt = s->owner_dt;  // "auto" force precision is decided during the build
+    struct DtScope { nbmi_sim *s; ~DtScope() { s->step_dt = 0.0; } } dt_scope{s};
     if (n_new > 0 && s->world == 1) {
         // one owner: the plain build (no dead rows, no boxes to publish)
         if (int rc = enqueue_local_sort(s, -1)) return rc;
@@ -3870,11 +4242,16 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
         if (int rc = enqueue_global_tree(s)) return rc;
         // where this rank's bodies are: boxes of the cells of its tree (see k_box_flags).  The node count lives on
         // the device: launch for the row budget, the kernels stop at num_nodes themselves.
-        const int64_t rows = s->own_node_rows;
-        k_box_flags<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_level, s->node_ref, s->hi_s, s->lo_s, s->info, n_new, rows, s->let_keep);
+        const int64_t rows = s->own_node_rows, ob = s->own_base;
+        NBMI_HIP_CHECK(hipMemsetAsync(s->chain_r, 0xff, sizeof(int32_t) * kChainLevels, st));
+        k_box_flags<<<nblocks(rows), kBlock, 0, st>>>(s->nodes + ob, s->node_level, s->node_ref, s->hi_s, s->lo_s, s->info, n_new, rows, s->let_keep,
+                                                     s->chain_r, ob);
         if (int rc = enqueue_iscan(s, s->let_keep, rows, s->let_scan)) return rc;
         NBMI_HIP_CHECK(hipMemsetAsync(s->let_ranges, 0, sizeof(int32_t) * 2 * kBoxesPerRank, st));
-        k_box_ranges<<<nblocks(rows), kBlock, 0, st>>>(s->nodes, s->node_ref, s->let_keep, s->let_scan, s->info, rows, n_new, s->let_ranges);
+        k_box_ranges<<<nblocks(rows), kBlock, 0, st>>>(s->nodes + ob, s->node_ref, s->let_keep, s->let_scan, s->info, rows, n_new, s->let_ranges, ob);
+        // what the other ranks need to know about this rank's two ends (travels with the boxes)
+        k_chain_table<<<1, 64, 0, st>>>(s->nodes + ob, s->node_ref, s->delta, s->S, s->T, s->hi_s, s->lo_s, n_new, s->info, s->chain_r, ob,
+                                        (ChainTable *)dev_chain);
         k_boxes_init<<<(6 * kBoxesPerRank + kBlock - 1) / kBlock, kBlock, 0, st>>>((double *)dev_boxes);
         k_range_boxes<<<(unsigned)((n_new + (int64_t)kBoxChunk * (kBlock / 64) - 1) / ((int64_t)kBoxChunk * (kBlock / 64))), kBlock, 0, st>>>(
             s->p64_s, s->let_ranges, s->let_scan + rows, n_new, (double *)dev_boxes);
@@ -3882,6 +4259,7 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
         std::vector<double> empty(6 * kBoxesPerRank);
         for (int k = 0; k < 6 * kBoxesPerRank; k++) empty[k] = (k % 6) < 3 ? INFINITY : -INFINITY;
         NBMI_HIP_CHECK(hipMemcpyAsync(dev_boxes, empty.data(), empty.size() * 8, hipMemcpyHostToDevice, st));
+        if (dev_chain) NBMI_HIP_CHECK(hipMemsetAsync(dev_chain, 0, sizeof(ChainTable), st));  // n = 0: no bodies, no part in the tree
         NBMI_HIP_CHECK(hipStreamSynchronize(st));  // `empty` dies here
     }
     NBMI_HIP_CHECK(hipGetLastError());
@@ -3893,43 +4271,64 @@ int nbmi_owner_adopt(nbmi_sim *s, const void *dev_recv_rows, int64_t n_recv, con
     return 0;
 }
 
-int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, void *dev_let, int64_t *counts /* world, host */) {
+// the float64 records as the exchange sees them: present whenever the handle's trees carry them
+static inline NodeD *let_nodesd(const nbmi_sim *s) { return s->force_prec != 1 ? s->nodesd : nullptr; }
+int nbmi_owner_let_row_bytes(void) { return kLetRow; }
+
+int nbmi_owner_set_dt(nbmi_sim *s, double dt) {
+    if (int rc = owner_check(s, "nbmi_owner_set_dt")) return rc;
+    if (!(dt >= 0.0)) { nbmi::set_error("nbmi_owner_set_dt: dt must be >= 0"); return NBMI_ERR_ARG; }
+    s->owner_dt = dt;
+    return 0;
+}
+
+int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, const void *dev_chains, void *dev_let, int64_t *counts /* world, host */) {
     if (int rc = owner_check(s, "nbmi_owner_export_let")) return rc;
-    if (!dev_boxes || !dev_let || !counts) { nbmi::set_error("nbmi_owner_export_let: null buffer"); return NBMI_ERR_ARG; }
+    if (!dev_boxes || !dev_let || !counts || (s->world > 1 && !dev_chains)) { nbmi::set_error("nbmi_owner_export_let: null buffer"); return NBMI_ERR_ARG; }
+    s->chains = (const ChainTable *)dev_chains;
     for (int j = 0; j < s->world; j++) counts[j] = 0;
     if (s->n == 0 || s->world == 1) return 0;
     hipStream_t st = s->stream;
-    const int64_t stride = s->let_stride;
+    const int64_t stride = s->let_stride, ob = s->own_base;
     const int W = s->world;
+    const ChainTable *T = s->chains;
+    // the own tree becomes this rank's piece of the global pre-order array (a few nodes change; up to 43 are added)
+    k_chain_fix<<<1, 64, 0, st>>>(T, W, s->rank, s->nodes + ob, s->nodes64 + ob, let_nodesd(s) ? let_nodesd(s) + ob : nullptr, s->node_level,
+                                  s->node_ref, s->chain_r, s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY, s->own_node_rows,
+                                  s->own_links, s->info);
+    NBMI_HIP_CHECK(hipMemcpyAsync(s->h_info, s->info, sizeof(TreeInfo), hipMemcpyDeviceToHost, st));  // (read after the wait below)
     // How many nodes the own tree has is known on the device; the host needs a launch bound.  The previous step's
     // count + 2 % is one (a tree changes by a few nodes in a thousand per step): no wait for this step's header
     // before the kernels are enqueued, ONE wait at the end for the counts - and the header, which says whether the
     // bound held (if not: once more with the exact count).
     int64_t nn = -1;
     if (s->last_nodes > 0 && !s->exchange_sync) {
-        nn = s->last_nodes + s->last_nodes / 50 + 4096;
+        nn = s->last_nodes + s->last_nodes / 50 + 4096;  // (covers the handful of cells k_chain_fix adds)
         if (nn > s->own_node_rows) nn = s->own_node_rows;
         if (getenv("NBMI_LET_UNDERESTIMATE")) nn = s->last_nodes / 2;  // test hook: forces the "bound did not hold" repeat
     }
     for (int attempt = 0; attempt < 2; attempt++) {
         if (nn < 0) {
-            NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));
+            NBMI_HIP_CHECK(hipStreamSynchronize(st));  // this step's header, behind k_chain_fix
             if (s->h_info->error) return check_device_error(s);
             nn = s->h_info->num_nodes;
         }
         NBMI_HIP_CHECK(hipMemsetAsync(s->let_diff, 0, (size_t)stride * W * 4, st));
         k_super_boxes<<<(W * kSupersPerRank + 63) / 64, 64, 0, st>>>((const double *)dev_boxes, W * kSupersPerRank, s->let_supers);
         k_rank_boxes<<<1, kMaxWorld * kMegasPerRank, 0, st>>>(s->let_supers, W, s->let_megas, s->let_rankbox);
-        k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes, s->nodes64, nn, (const double *)dev_boxes, s->let_supers, s->let_megas,
+        k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes + ob, s->nodes64 + ob, nn, (const double *)dev_boxes, s->let_supers, s->let_megas,
                                                   s->let_rankbox, W, s->rank, s->theta, s->softening * s->softening, s->let_diff, stride,
-                                                  s->info);
+                                                  s->info, ob);
+        k_let_mark_left<<<1, 64, 0, st>>>(T, W, s->rank, (const double *)dev_boxes, s->let_supers, s->let_megas, s->let_rankbox, s->theta,
+                                          s->softening * s->softening, s->let_diff, stride, s->info);
         if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
         k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep, s->info);
         if (int rc = enqueue_iscan(s, s->let_keep, nn, s->let_scan, W, stride)) return rc;
         k_let_counts<<<1, 64, 0, st>>>(s->let_scan, nn, stride, W, s->rank, s->let_counts);
-        k_let_compact<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->nodes, s->nodes64, s->let_keep, s->let_scan, nn, stride,
+        k_let_compact<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->nodes + ob, s->nodes64 + ob, let_nodesd(s) ? let_nodesd(s) + ob : nullptr,
+                                                                                s->node_level, s->own_links, T, s->let_keep, s->let_scan, nn, stride,
                                                                                 s->let_capacity, s->rank, s->let_counts + W, (char *)dev_let,
-                                                                                s->info);
+                                                                                s->info, ob);
         NBMI_HIP_CHECK(hipGetLastError());
         NBMI_HIP_CHECK(hipMemcpyAsync(counts, s->let_counts, (size_t)W * 8, hipMemcpyDeviceToHost, st));
         NBMI_HIP_CHECK(hipStreamSynchronize(st));  // the one wait: counts + (long since) this step's header
@@ -3954,7 +4353,7 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, do
     if (s->n == 0) return 0;
     hipStream_t st = s->stream;
     if (s->world == 1) {  // nothing received: the walk array is the own tree; an overflow freezes the walk and is reported at the next sync
-        k_let_finish<<<1, 1, 0, st>>>(s->nodes, -1, s->info);
+        k_let_finish_alone<<<1, 1, 0, st>>>(s->info);
         NBMI_HIP_CHECK(hipGetLastError());
         if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
         s->curbuf ^= 1;
@@ -3963,22 +4362,41 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, do
         return 0;
     }
     NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));  // (long complete: nbmi_owner_export_let waited behind it)
-    const TreeInfo &h = *s->h_info;
+    const TreeInfo &h = *s->h_info;  // as nbmi_owner_export_let left it: the own piece in its global form
     if (h.error) return check_device_error(s);
-    int64_t total = h.num_nodes, seen = 0;
-    for (int j = 0; j < s->world; j++) {  // the received trees are packed one after the other, in rank order
-        if (j == s->rank || counts[j] <= 0) continue;
-        if (total + counts[j] + 1 > s->node_capacity) {
-            nbmi::set_error("nbmi_owner_step: received trees do not fit (%lld + %lld of %lld rows)", (long long)total,
-                            (long long)counts[j], (long long)s->node_capacity);
-            return NBMI_ERR_CAPACITY;
-        }
-        k_let_append<<<nblocks(counts[j]), kBlock, 0, st>>>((const char *)dev_recv + seen * kLetRow, counts[j], total, s->nodes,
-                                                            s->nodes64);
-        total += counts[j];
-        seen += counts[j];
+    // the pieces in rank order: lower ranks packed up against the own piece, higher ranks behind it (see Pieces)
+    Pieces P;
+    const int W = s->world, me = s->rank;
+    int64_t lower = 0, upper = 0, seen = 0;
+    for (int j = 0; j < W; j++) {
+        if (j == me || counts[j] <= 0) continue;
+        if (j < me) lower += counts[j]; else upper += counts[j];
     }
-    k_let_finish<<<1, 1, 0, st>>>(s->nodes, total, s->info);
+    const int64_t own_first = s->own_base + h.own_skip, own_end = s->own_base + h.num_nodes;
+    if (lower + 1 > own_first || own_end + upper + 1 > s->node_capacity) {
+        nbmi::set_error("nbmi_owner_step: received trees do not fit (%lld rows in front of / %lld behind the own %lld of %lld rows)",
+                        (long long)lower, (long long)upper, (long long)h.num_nodes, (long long)s->node_capacity);
+        return NBMI_ERR_CAPACITY;
+    }
+    const int64_t walk_first = own_first - lower;
+    int64_t at_lo = walk_first, at_hi = own_end;
+    for (int j = 0; j < kMaxWorld; j++) { P.src[j] = nullptr; P.count[j] = 0; P.base[j] = 0; }
+    for (int j = 0; j < W; j++) {
+        if (j == me) { P.base[j] = own_first; continue; }
+        const int64_t c = counts[j] > 0 ? counts[j] : 0;
+        P.src[j] = (const char *)dev_recv + seen * kLetRow;
+        P.count[j] = c;
+        if (j < me) { P.base[j] = at_lo; at_lo += c; } else { P.base[j] = at_hi; at_hi += c; }
+        seen += c;
+    }
+    P.total = at_hi;
+    P.me = me;
+    NodeD *nd = let_nodesd(s);
+    for (int j = 0; j < W; j++) {
+        if (j == me || P.count[j] == 0) continue;
+        k_let_append<<<nblocks(P.count[j]), kBlock, 0, st>>>(P, j, s->nodes, s->nodes64, nd, s->info);
+    }
+    k_let_finish<<<1, 64, 0, st>>>(P, s->own_links, s->chains, s->own_base, walk_first, s->nodes, nd, s->info);
     NBMI_HIP_CHECK(hipGetLastError());
     if (int rc = enqueue_walk(s, true, dt, nullptr)) return rc;
     s->curbuf ^= 1;
@@ -4128,8 +4546,8 @@ int nbmi_set_force_precision(nbmi_sim *s, int mode, double tau) {
     }
     if (s->method != NBMI_METHOD_BARNES_HUT) { nbmi::set_error("not a Barnes-Hut handle"); return NBMI_ERR_ARG; }
     if (mode != 1 && !s->nodesd) {
-        if (s->owner || !(s->softening > 1e-12) || s->node_capacity + 2 > kMaxNodeDRows) {
-            nbmi::set_error("nbmi_set_force_precision: float64 forces need softening > 0, at most %lld node rows and a handle that is not in owner mode",
+        if (!(s->softening > 1e-12) || s->node_capacity + 2 > kMaxNodeDRows) {
+            nbmi::set_error("nbmi_set_force_precision: float64 forces need softening > 0 and at most %lld node rows",
                             (long long)kMaxNodeDRows);
             return NBMI_ERR_ARG;
         }

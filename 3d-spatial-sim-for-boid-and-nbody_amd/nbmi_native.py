@@ -50,12 +50,15 @@ PROTOTYPES = {
     "nbmi_create_owner": (_vp, [_i64, _vp, _vp, _vp, _vp, _i64, _i64, C.c_int, C.c_int, _dbl, _dbl, _dbl, _dbl, C.c_int]),
     "nbmi_owner_count": (_i64, [_vp]),
     "nbmi_owner_boxes_per_rank": (C.c_int, []),
+    "nbmi_owner_let_row_bytes": (C.c_int, []),
+    "nbmi_owner_set_dt": (C.c_int, [_vp, _dbl]),
     "nbmi_owner_get_ids": (C.c_int, [_vp, _vp]),
     "nbmi_owner_maxabs": (C.c_int, [_vp, _vp]),
     "nbmi_owner_sample": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "nbmi_owner_partition": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
-    "nbmi_owner_adopt": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
-    "nbmi_owner_export_let": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "nbmi_owner_adopt": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "nbmi_owner_chain_doubles": (C.c_int, []),
+    "nbmi_owner_export_let": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "nbmi_owner_step": (C.c_int, [_vp, _vp, _vp, _dbl]),
     "nbmi_visible_points": (C.c_int, [_vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),
     "nbmi_set_exchange_sync": (C.c_int, [_vp, C.c_int]),

@@ -383,16 +383,27 @@ class HIPOwnerSimulation(HIPBarnesHutSimulation):
                                                   _nat.ptr(counts)), "nbmi_owner_partition")
         return counts
 
-    def owner_adopt(self, dev_recv_rows, n_new, dev_maxabs, dev_bbox):
-        _nat.check(self._lib.nbmi_owner_adopt(self._h, int(dev_recv_rows), int(n_new), int(dev_maxabs), int(dev_bbox)),
+    def owner_adopt(self, dev_recv_rows, n_new, dev_maxabs, dev_bbox, dev_chain=0):
+        _nat.check(self._lib.nbmi_owner_adopt(self._h, int(dev_recv_rows), int(n_new), int(dev_maxabs), int(dev_bbox), int(dev_chain)),
                    "nbmi_owner_adopt")
 
-    def owner_export_let(self, dev_boxes, dev_let):
+    def chain_doubles(self):
+        """float64 words of a rank's boundary table (nbmi_owner_adopt writes it, all ranks' tables go to owner_export_let)."""
+        return int(self._lib.nbmi_owner_chain_doubles())
+
+    def owner_export_let(self, dev_boxes, dev_chains, dev_let):
         """Rows for every destination rank (packed in rank order in `dev_let`); returns the counts."""
         counts = np.zeros(self.world, dtype=np.int64)
-        _nat.check(self._lib.nbmi_owner_export_let(self._h, int(dev_boxes), int(dev_let), _nat.ptr(counts)),
+        _nat.check(self._lib.nbmi_owner_export_let(self._h, int(dev_boxes), int(dev_chains), int(dev_let), _nat.ptr(counts)),
                    "nbmi_owner_export_let")
         return counts
+
+    def owner_set_dt(self, dt):
+        """dt of the step about to be exchanged: force precision "auto" is decided while owner_adopt builds the tree."""
+        _nat.check(self._lib.nbmi_owner_set_dt(self._h, float(dt)), "nbmi_owner_set_dt")
+
+    def let_row_bytes(self):
+        return int(self._lib.nbmi_owner_let_row_bytes())
 
     def owner_step(self, dev_lets, counts, dt):
         counts = np.ascontiguousarray(counts, dtype=np.int64)

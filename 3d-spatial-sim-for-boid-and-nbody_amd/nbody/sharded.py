@@ -15,8 +15,9 @@ The reference is single-device; this is new design, in two forms:
   key range, so its waves stay compact), local sort + octree of the owned bodies inside the global cube,
   all-gather of the ranks' bounding boxes (tight boxes of the cells of each rank's own tree), pruning of
   the own tree against EACH other rank's boxes (the reference's opening test at the box's nearest point,
-  conservative by 1e-9), all-to-all-v of the pruned trees (56 B per node: the 24-byte walk record and its
-  float64 twin; a rank only receives what its own bodies can open), walk over own + received trees.
+  conservative by 1e-9), all-to-all-v of the pruned trees (48 B per node, float64 moments: the receiver rebuilds the fp32 and
+  the float64 walk record from them; a rank only receives what its own bodies can open), walk over own +
+  received trees with the handle's force precision ("auto" by default, as on one GPU).
   Per-rank sort / build / state no longer grow with the world size; only the received trees do.  Cells
   that straddle rank boundaries appear once per rank (partial cells), so positions agree with the 1-GPU
   run to a stated tolerance instead of bit for bit.
@@ -178,7 +179,7 @@ class HipLetEngine:
     """This rank's bodies in one owner-mode libnbmi handle; exchange buffers are torch CUDA tensors."""
 
     SAMPLES = 256        # key samples per rank for the splitters
-    LET_ROW_BYTES = 56   # 24-byte walk record + 32-byte float64 twin
+    LET_ROW_BYTES = 48   # float64 {cx, cy, cz, G m}, float s2t, uint next, float64 half size (nbmi_owner_let_row_bytes)
 
     def __init__(self, positions, velocities, masses, G, softening, damping, theta, device, rank, world):
         import torch
@@ -211,7 +212,12 @@ class HipLetEngine:
         nbox = 6 * int(self.sim._lib.nbmi_owner_boxes_per_rank())  # several boxes per rank: a key range is not a box
         self.bbox = z(nbox)
         self.boxes = z(world * nbox)
-        # trees travel as 56-byte rows (24-byte walk record + 32-byte float64 twin), one packed segment per rank
+        # what the other ranks need to know about this rank's two ends to cut ONE global octree into the ranks' pieces
+        nchain = self.sim.chain_doubles()
+        self.chain = z(nchain)
+        self.chains = z(world * nchain)
+        # trees travel as 48-byte float64 rows (both walk records are rebuilt from them), one packed segment per rank
+        self.LET_ROW_BYTES = self.sim.let_row_bytes()
         self.let_send = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
         self.let_recv = torch.zeros((max(let, 1), self.LET_ROW_BYTES), dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)  # the fills ran on torch's stream, the library has its own
@@ -228,6 +234,10 @@ class HipLetEngine:
         self.let_counts = np.zeros(world, dtype=np.int64)
 
     # ---- the six phases of a step (LetBarnesHut puts the collectives between them) ------------------
+    def op_begin(self, dt):
+        """dt of the step that starts: the tree build decides the waves' force precision with it."""
+        self.sim.owner_set_dt(dt)
+
     def op_maxabs(self):
         self.sim.owner_maxabs(self.maxabs.data_ptr())
 
@@ -239,10 +249,10 @@ class HipLetEngine:
 
     def op_adopt(self, rows, n_recv):
         """`n_recv` immigrant rows join the bodies that stayed; keys, sort, octree, boxes."""
-        self.sim.owner_adopt(rows.data_ptr(), n_recv, self.maxabs.data_ptr(), self.bbox.data_ptr())
+        self.sim.owner_adopt(rows.data_ptr(), n_recv, self.maxabs.data_ptr(), self.bbox.data_ptr(), self.chain.data_ptr())
 
     def op_export_let(self):
-        return self.sim.owner_export_let(self.boxes.data_ptr(), self.let_send.data_ptr())
+        return self.sim.owner_export_let(self.boxes.data_ptr(), self.chains.data_ptr(), self.let_send.data_ptr())
 
     def op_step(self, recv_counts, dt):
         self.sim.owner_step(self.let_recv.data_ptr(), recv_counts, dt)
@@ -296,6 +306,8 @@ class LetBarnesHut:
         e, W = self.engine, self.world
         for _ in range(substeps):
             wire = 0
+            if hasattr(e, "op_begin"):
+                e.op_begin(dt)
             e.op_maxabs()
             if W > 1:
                 self.comm.all_reduce_max(e.maxabs)
@@ -330,6 +342,9 @@ class LetBarnesHut:
             counts = np.zeros(W, dtype=np.int64)
             if W > 1:
                 self.comm.all_gather(e.boxes, e.bbox)
+                if hasattr(e, "chain"):
+                    self.comm.all_gather(e.chains, e.chain)
+                    wire += e.chain.numel() * 8
                 e.wait()
                 let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
                 room = e.let_recv.shape[0]

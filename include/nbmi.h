@@ -177,7 +177,8 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *        all-gather of the boxes                    (world x B x 6 doubles)
  *   nbmi_owner_export_let(h, boxes, let, counts)    prune the own tree against EACH other rank's boxes: counts[j] rows
  *                                                   for rank j, packed one destination after the other in `let`
- *                                                   (56-byte rows: the 24-byte walk record + its float64 twin;
+ *                                                   (rows of nbmi_owner_let_row_bytes() = 48 bytes, float64
+ *                                                   throughout: {cx, cy, cz, G m, float s2t, uint next, hs};
  *                                                   let_capacity rows in all); counts[world] on the host
  *        all-to-all of the counts, all-to-all-v of the rows
  *   nbmi_owner_step(h, recv, recv_counts, dt)       append the received trees (packed in rank order, at most
@@ -189,6 +190,13 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * default sync = 1 every call waits for its own work, as in round 2.  World size 1 skips the splitter, dead-row
  * and box work altogether.
  *
+ * Force precision [r3]: an owner handle computes forces like a plain one (nbmi_set_force_precision; default
+ * "auto") - the exchanged rows carry the float64 centre of mass and G m of every node, and the receiver builds
+ * both walk records from them.  "auto" is decided while nbmi_owner_adopt builds the tree, so the dt of the
+ * step has to be known by then: nbmi_owner_set_dt(h, dt) before nbmi_owner_adopt (no dt set: fp32 forces, as
+ * "auto" does for any build that is not part of a step).  Each rank decides for its own waves, and applies the
+ * "more than half of the waves" rule to its own bodies.
+ *
  * Getters of an owner handle return the owned bodies in their current (key) order; nbmi_owner_get_ids gives the
  * global body ids of those rows. */
 nbmi_sim *nbmi_create_owner(int64_t n, const double *positions_xyz, const double *velocities_xyz, const double *masses,
@@ -196,13 +204,17 @@ nbmi_sim *nbmi_create_owner(int64_t n, const double *positions_xyz, const double
                             double G, double softening, double damping, double theta, int device);
 int64_t nbmi_owner_count(nbmi_sim *sim);
 int nbmi_owner_boxes_per_rank(void);
+int nbmi_owner_let_row_bytes(void);
+int nbmi_owner_set_dt(nbmi_sim *sim, double dt);
 int nbmi_owner_get_ids(nbmi_sim *sim, int32_t *out);
 int nbmi_owner_maxabs(nbmi_sim *sim, void *dev_maxabs);
 int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples);
 int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
                          int64_t *counts_host);
-int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes);
-int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, void *dev_let, int64_t *counts_host);
+int nbmi_owner_chain_doubles(void);
+int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_recv, const void *dev_maxabs, void *dev_boxes,
+                     void *dev_chain);
+int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, const void *dev_chains, void *dev_let, int64_t *counts_host);
 int nbmi_owner_step(nbmi_sim *sim, const void *dev_recv_let, const int64_t *recv_counts_host, double dt);
 
 /* Render-side reduction: NBodySimulation._compute_visibility + the gather of

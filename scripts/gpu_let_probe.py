@@ -91,7 +91,7 @@ for W in Ws:
            "rank0_ms_total": round(sum(ph.values()) / k, 3), "rank0_owned": E[0].sim.n, "rank0_own_tree_nodes": own_nodes,
            "tree_rows_received_by_rank0": int(E[0].let_counts.sum()), "tree_rows_sent_by_rank0": int(lc[0].sum()),
            "rows_migrated_from_rank0": E[0].migrated,
-           "bytes_sent_by_rank0": int(lc[0].sum()) * 56 + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
+           "bytes_sent_by_rank0": int(lc[0].sum()) * E[0].LET_ROW_BYTES + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
     if W == Ws[0] and W == 1:
         single = HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta)
         single.step_many(dt, 2); single.sync()

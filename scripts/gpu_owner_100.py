@@ -1,0 +1,55 @@
+"""Owner mode (locally essential trees) over 100 steps: BASELINE config 2's 1 M-body galaxy on EIGHT virtual ranks
+(threads on one GPU, LetBarnesHut.step itself) against the float64 oracle trajectory of tests/cache
+(scripts/oracle_traj_cache.py), per force-precision mode.  Error = max |x - x_ref|_inf / max |x_ref|.
+
+    python scripts/gpu_owner_100.py [world] [modes]        -> one JSON line per (mode, checkpoint)
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "3d-spatial-sim-for-boid-and-nbody_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    modes = sys.argv[2].split(",") if len(sys.argv) > 2 else ["auto", "f32", "f64"]
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    from tools.presets import generate_distribution
+    from test_gpu_sharded_record import _ThreadComm, _run_ranks
+    n, dt, G, eps, theta = 1_000_000, 0.05, 0.07, 1.5, 0.5
+    np.random.seed(42)
+    pos, vel, mass = generate_distribution("galaxy", n, 800.0, 0.07)
+    keep = (10, 50, 100)
+    ref = {k: np.load(os.path.join(ROOT, "tests", "cache", f"oracle_galaxy_{n}_step{k}.npy")) for k in keep}
+    for mode in modes:
+        comm = _ThreadComm(world)
+        engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
+        for e in engines:
+            e.sim.set_force_precision(mode)
+        steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+        done = 0
+        for k in keep:
+            t0 = time.time()
+            out = _run_ranks(steppers, comm, dt, k - done)
+            wall = time.time() - t0
+            done = k
+            d = np.abs(out[0][0] - ref[k]).max(axis=1) / np.abs(ref[k]).max()
+            share = [e.sim.force_precision_share() for e in engines]
+            print(json.dumps({"mode": mode, "world": world, "steps": k, "max": float(d.max()),
+                              "p99.9": float(np.quantile(d, 0.999)), "above_1e-5": int((d > 1e-5).sum()),
+                              "float64_wave_share_by_rank": [round(float(s[0]), 3) for s in share],
+                              "all64_by_rank": [int(s[1]) for s in share],
+                              "let_rows_by_rank": [int(e.let_counts.sum()) for e in engines],
+                              "wall_s_for_these_steps": round(wall, 2)}), flush=True)
+        for e in engines:
+            e.sim.close()
+
+
+if __name__ == "__main__":
+    main()
