@@ -45,6 +45,7 @@ for W in Ws:
     for it in range(steps):
         rec = it >= 1  # first step: initial migration
         for e in E:
+            e.op_begin(dt)
             _, t = timed(e.op_maxabs)
             if rec and e.rank == 0: ph["maxabs"] += t
         mx = torch.stack([e.maxabs for e in E]).max(dim=0).values
@@ -68,10 +69,12 @@ for W in Ws:
             if rec and e.rank == 0: ph["adopt_sort_build"] += t
             e.migrated = int(sc[e.rank].sum())
         boxes = torch.cat([e.bbox for e in E])
+        chains = torch.cat([e.chain for e in E])
         lc = [np.zeros(W, dtype=np.int64) for _ in E]
         if W > 1:
             for e in E:
                 e.boxes.copy_(boxes)
+                e.chains.copy_(chains)
                 c, t = timed(e.op_export_let)
                 lc[e.rank] = c
                 if rec and e.rank == 0: ph["export_tree"] += t
@@ -91,7 +94,8 @@ for W in Ws:
            "rank0_ms_total": round(sum(ph.values()) / k, 3), "rank0_owned": E[0].sim.n, "rank0_own_tree_nodes": own_nodes,
            "tree_rows_received_by_rank0": int(E[0].let_counts.sum()), "tree_rows_sent_by_rank0": int(lc[0].sum()),
            "rows_migrated_from_rank0": E[0].migrated,
-           "bytes_sent_by_rank0": int(lc[0].sum()) * E[0].LET_ROW_BYTES + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8}
+           "bytes_sent_by_rank0": int(lc[0].sum()) * E[0].LET_ROW_BYTES + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8 + E[0].chain.numel() * 8,
+           "float64_wave_share_rank0": E[0].sim.force_precision_share()[0]}
     if W == Ws[0] and W == 1:
         single = HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta)
         single.step_many(dt, 2); single.sync()

@@ -597,7 +597,18 @@ def test_galaxy_200k_100_steps_meets_the_north_star_bound(gpu, oracle):
     sim.close()
 
 
+_ORACLE_1M = {}
+
+
 def _oracle_galaxy_1m(oracle, steps, keep):
+    """(memoised: the owner-mode test of tests/test_gpu_sharded_record.py asks for the same trajectory)"""
+    key = (steps, tuple(keep))
+    if key not in _ORACLE_1M:
+        _ORACLE_1M[key] = _oracle_galaxy_1m_compute(oracle, steps, keep)
+    return _ORACLE_1M[key]
+
+
+def _oracle_galaxy_1m_compute(oracle, steps, keep):
     """Oracle positions of BASELINE config 2 after the steps in `keep`: from tests/cache/ (scripts/oracle_traj_cache.py,
     same strict-IEEE build: bit-identical on any x86 host) when the files travelled with the tree, else computed here
     (about 2.3 s per step on 32 host threads)."""
