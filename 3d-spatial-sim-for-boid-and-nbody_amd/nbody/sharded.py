@@ -18,9 +18,9 @@ The reference is single-device; this is new design, in two forms:
   conservative by 1e-9), all-to-all-v of the pruned trees (48 B per node, float64 moments: the receiver rebuilds the fp32 and
   the float64 walk record from them; a rank only receives what its own bodies can open), walk over own +
   received trees with the handle's force precision ("auto" by default, as on one GPU).
-  Per-rank sort / build / state no longer grow with the world size; only the received trees do.  Cells
-  that straddle rank boundaries appear once per rank (partial cells), so positions agree with the 1-GPU
-  run to a stated tolerance instead of bit for bit.
+  Per-rank sort / build / state no longer grow with the world size; only the received trees do.  The
+  ranks' trees are pieces of ONE global octree (cells that span ranks carry global moments; each rank's
+  boundary table travels with its boxes): every body visits the 1-GPU run's accepted nodes in the 1-GPU order.
 
 Collectives are ``torch.distributed`` calls on device buffers (backend "nccl" = RCCL over xGMI), behind a
 small comm interface so that tests can play the ranks with threads on one GPU.

@@ -154,11 +154,16 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * (compute_bounds over the whole system, simulation.py:308-317) and walks its own tree plus, behind it in the
  * same node array, the part of every other rank's tree that some body of this rank can open (the other ranks
  * prune their trees against this rank's bounding boxes with the reference's own opening test, made conservative
- * by 1e-9).  Per-rank sort / build / memory no longer grow with the number of ranks.  Cells that straddle a
- * rank boundary are seen as one partial cell per rank instead of one whole cell, so positions agree with
- * the single-GPU run to a tolerance (measured 1.1e-7 of the largest coordinate after 5 steps at 60 k bodies on
- * three ranks; the tests bound it by 1e-6), not bit for bit;
- * the replicated-tree exchange above (nbmi_set_shard) stays as the bit-exact mode.
+ * by 1e-9).  Per-rank sort / build / memory no longer grow with the number of ranks.  [r3] The ranks' trees are
+ * pieces of ONE global octree: every rank publishes a small table about its first and last bodies
+ * (nbmi_owner_chain_doubles() doubles, written by nbmi_owner_adopt, all-gathered like the boxes), and
+ * nbmi_owner_export_let first turns the own tree into the rank's piece of the global pre-order node array - cells
+ * that reach into higher ranks get the global moments, cells that exist only across a boundary are inserted, the
+ * copies of cells that begin on a lower rank are dropped.  nbmi_owner_step puts the received pieces around the own
+ * one in rank order.  Every body then visits the single-GPU run's accepted nodes in the single-GPU order: with
+ * float64 forces the result equals the single handle's to rounding (tests: 1e-13 after 4 steps), in the default
+ * "auto" precision 1 M bodies on 8 ranks stay within 1.4e-5 of the float64 reference after 100 steps.
+ * The replicated-tree exchange above (nbmi_set_shard) stays as the bit-for-bit mode.
  *
  * One step, host side (buffers are DEVICE pointers; the collectives are the host framework's):
  *   nbmi_owner_maxabs(h, m)                         m <- max |coordinate| of the owned bodies (1 double)
@@ -169,20 +174,22 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  *                                                   the bodies that now belong to ANOTHER rank, grouped by destination
  *                                                   in `send`; counts[world] on the host (counts[own rank] = 0)
  *        all-to-all of the counts, all-to-all-v of the rows  (only bodies that crossed a splitter travel)
- *   nbmi_owner_adopt(h, recv, n_recv, m, box)       the n_recv received rows join the bodies that stayed: keys, sort, octree;
+ *   nbmi_owner_adopt(h, recv, n_recv, m, box, chain)   the n_recv received rows join the bodies that stayed: keys, sort, octree;
  *                                                   box <- B = nbmi_owner_boxes_per_rank() bounding boxes (6 doubles
  *                                                   each: lo xyz, hi xyz) of the bodies inside cells of the own
  *                                                   tree (level 4, refined to level 11 along the two boundary
  *                                                   chains), in key order; unused boxes are empty (lo > hi)
- *        all-gather of the boxes                    (world x B x 6 doubles)
- *   nbmi_owner_export_let(h, boxes, let, counts)    prune the own tree against EACH other rank's boxes: counts[j] rows
+ *                                                   chain <- the rank's boundary table (nbmi_owner_chain_doubles() doubles)
+ *        all-gather of the boxes, all-gather of the tables   (world x B x 6 doubles, world x C doubles)
+ *   nbmi_owner_export_let(h, boxes, chains, let, counts)   the own tree becomes the rank's piece of the global tree, then is
+ *                                                   pruned against EACH other rank's boxes: counts[j] rows
  *                                                   for rank j, packed one destination after the other in `let`
  *                                                   (rows of nbmi_owner_let_row_bytes() = 48 bytes, float64
- *                                                   throughout: {cx, cy, cz, G m, float s2t, uint next, hs};
+ *                                                   throughout: {cx, cy, cz, G m, float s2t, link, node index, level};
  *                                                   let_capacity rows in all); counts[world] on the host
  *        all-to-all of the counts, all-to-all-v of the rows
- *   nbmi_owner_step(h, recv, recv_counts, dt)       append the received trees (packed in rank order, at most
- *                                                   let_capacity rows) behind the own one, walk, kick-drift
+ *   nbmi_owner_step(h, recv, recv_counts, dt)       put the received pieces (packed in rank order, at most
+ *                                                   let_capacity rows) around the own one, walk, kick-drift
  *
  * Host waits [r3]: with nbmi_set_exchange_sync(h, 0) and the collectives enqueued ON the handle's stream
  * (nbmi_stream; torch.cuda.ExternalStream), nbmi_owner_maxabs / _sample / _adopt / _step only enqueue; the two

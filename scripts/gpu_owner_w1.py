@@ -22,7 +22,6 @@ np.random.seed(42)
 p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
 out = {}
 plain = HIPBarnesHutSimulation(p, v, m, 0.07, 1.5, 1.0, 0.5)
-plain.set_force_precision("f32")
 plain.step_many(0.05, 3)
 plain.sync()
 t0 = time.perf_counter()
