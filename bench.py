@@ -466,8 +466,8 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
     par = "single GPU"
     if world > 1 or use_dist:
         par = {"rows": f"x{world}: key-range shards, replicated state and tree, all-gather of 64-B rows",
-               "let": f"x{world}: key-range owners, body migration (all-to-all-v), per-rank octree in the global cube, "
-                      "all-to-all-v of locally essential trees",
+               "let": f"x{world}: key-range owners, body migration (all-to-all-v), one global octree cut into the ranks' pieces, "
+                      "all-to-all-v of the locally essential part of every piece",
                }.get(shard_mode, shard_mode) if method == "barnes_hut" else \
             f"x{world}: body-index shards of the all-pairs kernel, all-gather of 64-B rows"
     out = {
