@@ -1,0 +1,56 @@
+"""Config 4 in its north-star form: the 10 M-body collision (theta 0.5, dt 0.25) owned by EIGHT ranks of 1.25 M bodies
+(threads on one GPU through LetBarnesHut.step itself) against the uncapped oracle's trajectory of
+scripts/oracle_traj_cache_10m.py (every 16th body at steps 10 / 20 / 50 / 100 under tests/cache/).
+Error = max |x - x_ref|_inf / max |x_ref|.      python scripts/gpu_owner_10m.py [world] [mode]
+"""
+import glob
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "3d-spatial-sim-for-boid-and-nbody_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    mode = sys.argv[2] if len(sys.argv) > 2 else "auto"
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    from tools.presets import generate_distribution
+    from test_gpu_sharded_record import _ThreadComm, _run_ranks
+    n, dt, G, eps, theta = 10_000_000, 0.25, 0.08, 6.0, 0.5
+    snaps = {}
+    for f in glob.glob(os.path.join(ROOT, "tests", "cache", f"oracle_collision_{n}_step*_every16.npy")):
+        snaps[int(re.search(r"step(\d+)_", f).group(1))] = f
+    np.random.seed(42)
+    pos, vel, mass = generate_distribution("collision", n, 2000.0, 0.08)
+    comm = _ThreadComm(world)
+    engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
+    for e in engines:
+        e.sim.set_force_precision(mode)
+    steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    done = 0
+    for k in sorted(snaps):
+        t0 = time.time()
+        out = _run_ranks(steppers, comm, dt, k - done)
+        wall = time.time() - t0
+        ref = np.load(snaps[k])
+        d = np.abs(out[0][0][::16] - ref).max(axis=1) / np.abs(ref).max()
+        share = [e.sim.force_precision_share() for e in engines]
+        print(json.dumps({"workload": "collision_10m", "mode": mode, "world": world, "steps": k, "max": float(d.max()),
+                          "p99.9": float(np.quantile(d, 0.999)), "above_1e-5": int((d > 1e-5).sum()), "bodies_compared": len(d),
+                          "all64_by_rank": [int(s[1]) for s in share], "owned_by_rank": [int(e.sim.n) for e in engines],
+                          "let_rows_by_rank": [int(e.let_counts.sum()) for e in engines],
+                          "wall_s_per_step_all_ranks_on_one_gpu": round(wall / (k - done), 4)}), flush=True)
+        done = k
+    for e in engines:
+        e.sim.close()
+
+
+if __name__ == "__main__":
+    main()
