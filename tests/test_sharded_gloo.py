@@ -91,6 +91,10 @@ class OracleLetEngine:
         self.send_rows = torch.zeros((self.cap, 8), dtype=f64)
         self.recv_rows = torch.zeros((self.cap, 8), dtype=f64)
         self.bbox, self.boxes = torch.zeros(6, dtype=f64), torch.zeros(world * 6, dtype=f64)
+        # the product's engine also publishes a table about its first / last bodies with the boxes (one global octree
+        # cut into the ranks' pieces); the stand-in walks one tree per rank and only carries a recognisable table
+        # through the same collective
+        self.chain, self.chains = torch.zeros(4, dtype=f64), torch.zeros(world * 4, dtype=f64)
         self.let_send = torch.zeros((self.cap * world, 4), dtype=f64)
         self.let_recv = torch.zeros((self.cap * world, 4), dtype=f64)
         self.wire_bytes, self.migrated, self.let_counts = 0, 0, np.zeros(world, dtype=np.int64)
@@ -137,10 +141,13 @@ class OracleLetEngine:
         lo = self.pos.min(axis=0) if n_new else np.full(3, np.inf)
         hi = self.pos.max(axis=0) if n_new else np.full(3, -np.inf)
         self.bbox.copy_(torch.from_numpy(np.concatenate([lo, hi])))
+        self.chain.copy_(torch.tensor([float(self.rank), float(n_new), 0.0, 1.0], dtype=torch.float64))
 
     def op_export_let(self):
         # the same (unpruned) tree for every other rank, packed one destination after the other
         n = len(self.pos)
+        got = self.chains.view(self.world, 4).numpy()
+        assert np.array_equal(got[:, 0], np.arange(self.world)) and got[self.rank, 1] == n and (got[:, 3] == 1.0).all(), got
         rows = torch.from_numpy(np.concatenate([self.pos, self.mass[:, None]], axis=1))
         counts, off = np.zeros(self.world, dtype=np.int64), 0
         for j in range(self.world):
