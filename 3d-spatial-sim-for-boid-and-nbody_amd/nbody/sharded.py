@@ -302,6 +302,19 @@ class LetBarnesHut:
             return M[:, self.rank].copy(), M[:, :W], M[:, W:]
         return self.comm.all_to_all_counts(send_counts), None, None
 
+    def _raise_together(self, failed, extras, col, phase):
+        """`failed`: this rank's own exception of the phase (or None); extras[:, col]: every rank's failure flag."""
+        if extras is None:
+            if failed is not None:
+                raise failed
+            return
+        bad = np.nonzero(extras[:, col])[0]
+        if len(bad):
+            msg = f"owner mode: rank(s) {bad.tolist()} failed in the {phase} phase (every rank raises this together)"
+            if failed is not None:
+                raise RuntimeError(f"{msg}: {failed}") from failed
+            raise RuntimeError(msg)
+
     def _step(self, dt, substeps):
         e, W = self.engine, self.world
         for _ in range(substeps):
@@ -320,12 +333,21 @@ class LetBarnesHut:
                 e.wait()
                 wire += 8 * e.SAMPLES
                 allsamp = e.all_samples
-            send_counts = e.op_partition(allsamp)  # rows of the bodies that leave, grouped by destination
+            # A failure inside one rank's library call (the tree of the last step overflowed, a sort timed out ...) is
+            # carried through the next exchange of counts as a flag: every rank raises, none is left in a collective
+            failed = None
+            try:
+                send_counts = e.op_partition(allsamp)  # rows of the bodies that leave, grouped by destination
+            except RuntimeError as exc:
+                if W == 1:
+                    raise
+                failed, send_counts = exc, np.zeros(W, dtype=np.int64)
             n_recv = 0
             if W > 1:
                 held = e.sim.n if hasattr(e, "sim") else 0  # (a stand-in engine has no row budget: 0 rows of "infinity")
                 room = e.cap if hasattr(e, "sim") else (1 << 62)
-                recv_counts, M, ex = self._exchange_counts(send_counts, [held, room])
+                recv_counts, M, ex = self._exchange_counts(send_counts, [held, room, 1 if failed else 0])
+                self._raise_together(failed, ex, 2, "partition")
                 if M is not None:
                     # every rank checks EVERY rank's body rows against THAT rank's budget and raises with it
                     after = ex[:, 0] + M.sum(axis=0)  # rows a rank holds while it adopts: stayers, leavers' rows, arrivals
@@ -346,9 +368,13 @@ class LetBarnesHut:
                     self.comm.all_gather(e.chains, e.chain)
                     wire += e.chain.numel() * 8
                 e.wait()
-                let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
+                try:
+                    let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
+                except RuntimeError as exc:
+                    failed, let_counts = exc, np.zeros(W, dtype=np.int64)
                 room = e.let_recv.shape[0]
-                counts, M, ex = self._exchange_counts(let_counts, [room])
+                counts, M, ex = self._exchange_counts(let_counts, [room, 1 if failed else 0])
+                self._raise_together(failed, ex, 1, "tree export")
                 if M is not None:  # the same verdict on every rank
                     incoming = M.sum(axis=0)
                     if (incoming > ex[:, 0]).any():
