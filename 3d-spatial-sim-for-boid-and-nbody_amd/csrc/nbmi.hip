@@ -3137,6 +3137,11 @@ struct nbmi_sim {
     double step_dt = 0.0;                // dt of the step being enqueued (0: a build without a step)
     double owner_dt = 0.0;               // owner mode: the dt the next nbmi_owner_step will use (nbmi_owner_set_dt; "auto" needs it at build time)
     int balance_blocks = 0;           // the block count the bounds on the device were made for (0: none yet)
+    // the cuts for the NEXT walk are made on a stream of their own, beside the next step's build (one workgroup, 70 us
+    // at 10 M bodies: off the critical path)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_walked = nullptr, ev_cut = nullptr;
+    bool cut_pending = false;         // a k_xcd_bounds on `side` that the next balanced walk has to wait for
     int walk_block = kBlock;  // threads per walk block (64, 128 or 256; measurement knob NBMI_WALK_BLOCK)
     int sort_bits = 0;   // upper-word bits the radix sort looks at (0: chosen from n; NBMI_SORT_BITS); widened when long runs show up
     bool maxabs_fused = false;  // TreeInfo::maxabs_next holds max |coordinate| of the CURRENT positions (set by a full
@@ -3389,15 +3394,30 @@ int enqueue_walk(nbmi_sim *s, bool integrate, double dt, double *acc_out) {
                          P.rank_begin == 0 && P.rank_end == n && getenv("NBMI_XCD_CHUNK") == nullptr;
     if (balance) {
         const int jmax = ((gb + 7) / 8) * 3 / 2 + 1;
+        if (s->cut_pending) {  // the cuts made from the last walk's times (on the side stream)
+            NBMI_HIP_CHECK(hipStreamWaitEvent(st, s->ev_cut, 0));
+            s->cut_pending = false;
+        }
         if (s->balance_blocks != gb) {  // first use (or another shard size): no times yet -> equal eighths
             NBMI_HIP_CHECK(hipMemsetAsync(s->wave_cycles, 0, (size_t)gb * 16, st));
             k_xcd_bounds<<<1, 1024, 0, st>>>(s->wave_cycles, gb, jmax, s->xcd_bounds);
             s->balance_blocks = gb;
         }
         P.balance = 1;
+        if (!s->side) {
+            NBMI_HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            NBMI_HIP_CHECK(hipEventCreateWithFlags(&s->ev_walked, hipEventDisableTiming));
+            NBMI_HIP_CHECK(hipEventCreateWithFlags(&s->ev_cut, hipEventDisableTiming));
+        }
         k_walk<true, false, false><<<8 * jmax, wb, 0, st>>>(s->nodes, s->wtab, s->info, s->posm_s, s->perm, acc_out, P, s->info);
-        k_xcd_bounds<<<1, 1024, 0, st>>>(s->wave_cycles, gb, jmax, s->xcd_bounds);  // cuts for the next step
         NBMI_HIP_CHECK(hipGetLastError());
+        // cuts for the next step: beside whatever the main stream does next (the next step's keys, sort and build)
+        NBMI_HIP_CHECK(hipEventRecord(s->ev_walked, st));
+        NBMI_HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_walked, 0));
+        k_xcd_bounds<<<1, 1024, 0, s->side>>>(s->wave_cycles, gb, jmax, s->xcd_bounds);
+        NBMI_HIP_CHECK(hipGetLastError());
+        NBMI_HIP_CHECK(hipEventRecord(s->ev_cut, s->side));
+        s->cut_pending = true;
         return 0;
     }
     if (integrate) {
@@ -3498,6 +3518,12 @@ void nbmi_destroy(nbmi_sim *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->side) {
+        (void)hipStreamSynchronize(s->side);
+        (void)hipStreamDestroy(s->side);
+        (void)hipEventDestroy(s->ev_walked);
+        (void)hipEventDestroy(s->ev_cut);
+    }
     for (void *p : s->allocs) (void)hipFree(p);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
