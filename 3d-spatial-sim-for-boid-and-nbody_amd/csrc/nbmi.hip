@@ -2279,13 +2279,16 @@ namespace {
 constexpr int kMaxWorld = 64;
 constexpr int kSampleCap = 4096;  // world x samples_per_rank, ranked in LDS
 
-// regular samples of the (nearly key-ordered) local keys
-__global__ __launch_bounds__(kBlock) void k_key_samples(const uint64_t *__restrict__ key_hi, int64_t n, int nsamples,
+// `nvalid` regular samples of the (nearly key-ordered) local keys; the other slots are all ones (ignored: they sort to
+// the very end).  [r3] A rank emits samples IN PROPORTION to the bodies it holds: with the same number from every rank
+// the pooled samples describe "one W-th of the bodies per rank" whatever the ranks actually hold, equal quantiles then
+// reproduce the current counts, and an imbalance, once there, stays (measured: 27 k ... 49 k bodies per rank after 500
+// steps of a 300 k-body collision on 8 ranks).
+__global__ __launch_bounds__(kBlock) void k_key_samples(const uint64_t *__restrict__ key_hi, int64_t n, int nsamples, int nvalid,
                                                         uint64_t *__restrict__ out) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= nsamples) return;
-    // an empty rank contributes nothing: its samples sort to the very end and are ignored (all ones)
-    out[k] = n > 0 ? key_hi[(int64_t)((2 * (int64_t)k + 1) * n / (2 * (int64_t)nsamples))] : ~0ull;
+    out[k] = (n > 0 && k < nvalid) ? key_hi[(int64_t)((2 * (int64_t)k + 1) * n / (2 * (int64_t)nvalid))] : ~0ull;
 }
 
 // world - 1 splitters at equal quantiles of the valid samples: every sample finds its rank among all of them by
@@ -4159,7 +4162,7 @@ int nbmi_owner_maxabs(nbmi_sim *s, void *dev_maxabs) {
     return 0;
 }
 
-int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, int nsamples) {
+int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, int nsamples, int nvalid) {
     if (int rc = owner_check(s, "nbmi_owner_sample")) return rc;
     if (!dev_maxabs || !dev_samples || nsamples < 1 || (int64_t)nsamples * s->world > kSampleCap) {
         nbmi::set_error("nbmi_owner_sample: bad arguments (at most %d samples over all ranks)", kSampleCap);
@@ -4171,7 +4174,8 @@ int nbmi_owner_sample(nbmi_sim *s, const void *dev_maxabs, void *dev_samples, in
     Bodies cur = s->buf[s->curbuf];
     if (s->n > 0 && s->hilbert) k_keys<true><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
     else if (s->n > 0) k_keys<false><<<nblocks(s->n), kBlock, 0, st>>>(cur.x, cur.y, cur.z, s->n, s->info, s->key_hi, s->key_lo, s->idx);
-    k_key_samples<<<(nsamples + kBlock - 1) / kBlock, kBlock, 0, st>>>(s->key_hi, s->n, nsamples, (uint64_t *)dev_samples);
+    if (nvalid < 1 || nvalid > nsamples) nvalid = nsamples;
+    k_key_samples<<<(nsamples + kBlock - 1) / kBlock, kBlock, 0, st>>>(s->key_hi, s->n, nsamples, nvalid, (uint64_t *)dev_samples);
     NBMI_HIP_CHECK(hipGetLastError());
     if (s->exchange_sync) NBMI_HIP_CHECK(hipStreamSynchronize(st));
     return 0;

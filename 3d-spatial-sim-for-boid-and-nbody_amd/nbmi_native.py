@@ -54,7 +54,7 @@ PROTOTYPES = {
     "nbmi_owner_set_dt": (C.c_int, [_vp, _dbl]),
     "nbmi_owner_get_ids": (C.c_int, [_vp, _vp]),
     "nbmi_owner_maxabs": (C.c_int, [_vp, _vp]),
-    "nbmi_owner_sample": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "nbmi_owner_sample": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
     "nbmi_owner_partition": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "nbmi_owner_adopt": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "nbmi_owner_chain_doubles": (C.c_int, []),

@@ -374,8 +374,10 @@ class HIPOwnerSimulation(HIPBarnesHutSimulation):
     def owner_maxabs(self, dev_maxabs):
         _nat.check(self._lib.nbmi_owner_maxabs(self._h, int(dev_maxabs)), "nbmi_owner_maxabs")
 
-    def owner_sample(self, dev_maxabs, dev_samples, nsamples):
-        _nat.check(self._lib.nbmi_owner_sample(self._h, int(dev_maxabs), int(dev_samples), int(nsamples)), "nbmi_owner_sample")
+    def owner_sample(self, dev_maxabs, dev_samples, nsamples, nvalid=0):
+        """`nvalid` of the `nsamples` slots get a key sample (0: all of them)."""
+        _nat.check(self._lib.nbmi_owner_sample(self._h, int(dev_maxabs), int(dev_samples), int(nsamples), int(nvalid)),
+                   "nbmi_owner_sample")
 
     def owner_partition(self, dev_all_samples, total, dev_send_rows):
         counts = np.zeros(self.world, dtype=np.int64)

@@ -242,7 +242,11 @@ class HipLetEngine:
         self.sim.owner_maxabs(self.maxabs.data_ptr())
 
     def op_sample(self):
-        self.sim.owner_sample(self.maxabs.data_ptr(), self.samples.data_ptr(), self.SAMPLES)
+        # samples in proportion to the bodies held (a rank at 1.25 x its share fills every slot): equal quantiles of
+        # the pooled samples are then equal shares of the BODIES, and an imbalance is corrected in one step
+        share = max(1.0, self.n_total / self.world)
+        nvalid = int(round(0.8 * self.SAMPLES * self.sim.n / share))
+        self.sim.owner_sample(self.maxabs.data_ptr(), self.samples.data_ptr(), self.SAMPLES, max(1, min(self.SAMPLES, nvalid)))
 
     def op_partition(self, all_samples):
         return self.sim.owner_partition(all_samples.data_ptr(), all_samples.numel(), self.send_rows.data_ptr())

@@ -168,7 +168,9 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * One step, host side (buffers are DEVICE pointers; the collectives are the host framework's):
  *   nbmi_owner_maxabs(h, m)                         m <- max |coordinate| of the owned bodies (1 double)
  *        all-reduce MAX of m
- *   nbmi_owner_sample(h, m, samples, S)             keys of the owned bodies in the global cube; S regular samples
+ *   nbmi_owner_sample(h, m, samples, S, V)          keys of the owned bodies in the global cube; V <= S regular samples
+ *                                                   (the other slots all ones = ignored).  V in proportion to the rank's
+ *                                                   body count, e.g. 0.8 S n_rank world / n_total, keeps the ranks balanced
  *        all-gather of the samples                  (world x S keys)
  *   nbmi_owner_partition(h, all, world*S, send, counts)   splitters at equal quantiles; rows {x,y,z,vx,vy,vz,m,id} of
  *                                                   the bodies that now belong to ANOTHER rank, grouped by destination
@@ -215,7 +217,7 @@ int nbmi_owner_let_row_bytes(void);
 int nbmi_owner_set_dt(nbmi_sim *sim, double dt);
 int nbmi_owner_get_ids(nbmi_sim *sim, int32_t *out);
 int nbmi_owner_maxabs(nbmi_sim *sim, void *dev_maxabs);
-int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples);
+int nbmi_owner_sample(nbmi_sim *sim, const void *dev_maxabs, void *dev_samples, int nsamples, int nvalid);
 int nbmi_owner_partition(nbmi_sim *sim, const void *dev_all_samples, int total_samples, void *dev_send_rows,
                          int64_t *counts_host);
 int nbmi_owner_chain_doubles(void);
