@@ -42,6 +42,7 @@ for W in Ws:
     with contextlib.redirect_stdout(sys.stderr):
         E = [HipLetEngine(p, v, m, G, eps, 1.0, theta, 0, r, W) for r in range(W)]
     ph = {k: 0.0 for k in ("maxabs", "sample", "partition", "adopt_sort_build", "export_tree", "walk")}
+    walk_by_rank = [0.0] * W
     for it in range(steps):
         rec = it >= 1  # first step: initial migration
         for e in E:
@@ -88,6 +89,7 @@ for W in Ws:
             e.let_counts = rc
             _, t = timed(lambda: (e.op_step(rc, dt), e.sim.sync()))
             if rec and e.rank == 0: ph["walk"] += t
+            if rec: walk_by_rank[e.rank] += t
     k = steps - 1
     own_nodes = E[0].sim.tree_stats(depth=False)["num_nodes"]
     row = {"world": W, "bodies_per_rank": per, "rank0_ms": {a: round(b / k, 3) for a, b in ph.items()},
@@ -95,7 +97,9 @@ for W in Ws:
            "tree_rows_received_by_rank0": int(E[0].let_counts.sum()), "tree_rows_sent_by_rank0": int(lc[0].sum()),
            "rows_migrated_from_rank0": E[0].migrated,
            "bytes_sent_by_rank0": int(lc[0].sum()) * E[0].LET_ROW_BYTES + E[0].migrated * ROW * 8 + 8 + 8 * E[0].SAMPLES + E[0].bbox.numel() * 8 + E[0].chain.numel() * 8,
-           "float64_wave_share_rank0": E[0].sim.force_precision_share()[0]}
+           "float64_wave_share_rank0": E[0].sim.force_precision_share()[0],
+           "walk_ms_by_rank": [round(t / k, 3) for t in walk_by_rank], "owned_by_rank": [int(e.sim.n) for e in E],
+           "float64_wave_share_by_rank": [round(e.sim.force_precision_share()[0], 3) for e in E]}
     if W == Ws[0] and W == 1:
         single = HIPBarnesHutSimulation(p, v, m, G, eps, 1.0, theta)
         single.step_many(dt, 2); single.sync()
