@@ -2837,7 +2837,7 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
 }
 // The cells that begin on a lower rank and reach into this one: their owner decides with the global moments whether
 // a destination needs their subtree; this rank takes the same decision from the same numbers (chain_cell) for the
-// part of the subtree that lies in ITS array: nodes [0, Ln[level]).  One wave, lane = level.
+// part of the subtree that lies in ITS array: nodes [0, Ln[level]).  One wave per destination rank, lane = level.
 __global__ void k_let_mark_left(const ChainTable *__restrict__ T, int world, int me, const double *__restrict__ boxes,
                                 const double *__restrict__ supers, const double *__restrict__ megas,
                                 const double *__restrict__ rankbox, double theta, double eps2, int32_t *__restrict__ diff,
@@ -2854,13 +2854,12 @@ __global__ void k_let_mark_left(const ChainTable *__restrict__ T, int world, int
     const double size = c.hs * 2.0;
     const double thr = (size / theta) * (size / theta) * (1.0 + 1e-9);
     const int64_t end = t.Lc[lev] < t.n ? t.Ln[lev] : info->num_nodes;
-    for (int j = 0; j < world; j++) {
-        if (j == me) continue;
-        if (!rank_may_open(j, c, eps2, thr, boxes, supers, megas, rankbox)) {
-            int32_t *d = diff + (int64_t)j * stride;
-            atomicAdd(&d[0], 1);
-            atomicAdd(&d[end], -1);
-        }
+    const int j = blockIdx.x;
+    if (j == me) return;
+    if (!rank_may_open(j, c, eps2, thr, boxes, supers, megas, rankbox)) {
+        int32_t *d = diff + (int64_t)j * stride;
+        atomicAdd(&d[0], 1);
+        atomicAdd(&d[end], -1);
     }
 }
 __global__ __launch_bounds__(kBlock) void k_let_keep(const int32_t *__restrict__ diff, const int32_t *__restrict__ diff_ex,
@@ -4333,7 +4332,7 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, const void *dev_ch
         k_let_mark<<<nblocks(nn), kBlock, 0, st>>>(s->nodes + ob, s->nodes64 + ob, nn, (const double *)dev_boxes, s->let_supers, s->let_megas,
                                                   s->let_rankbox, W, s->rank, s->theta, s->softening * s->softening, s->let_diff, stride,
                                                   s->info, ob);
-        k_let_mark_left<<<1, 64, 0, st>>>(T, W, s->rank, (const double *)dev_boxes, s->let_supers, s->let_megas, s->let_rankbox, s->theta,
+        k_let_mark_left<<<W, 64, 0, st>>>(T, W, s->rank, (const double *)dev_boxes, s->let_supers, s->let_megas, s->let_rankbox, s->theta,
                                           s->softening * s->softening, s->let_diff, stride, s->info);
         if (int rc = enqueue_iscan(s, s->let_diff, nn, s->let_scan, W, stride)) return rc;
         k_let_keep<<<dim3((unsigned)nblocks(nn), (unsigned)W), kBlock, 0, st>>>(s->let_diff, s->let_scan, nn, stride, s->let_keep, s->info);
@@ -4375,6 +4374,7 @@ int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, do
         s->maxabs_fused = s->fuse_maxabs;  // the walk left max |coordinate| of what it wrote
         return 0;
     }
+    if (!s->chains) { nbmi::set_error("nbmi_owner_step: call nbmi_owner_export_let first (it cuts the own tree to its piece of the global one)"); return NBMI_ERR_ARG; }
     NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));  // (long complete: nbmi_owner_export_let waited behind it)
     const TreeInfo &h = *s->h_info;  // as nbmi_owner_export_let left it: the own piece in its global form
     if (h.error) return check_device_error(s);
