@@ -24,7 +24,12 @@ Ws = [int(w) for w in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4
 G, eps, theta, dt, steps = 0.07, 1.5, 0.5, 0.05, 4
 
 
+_thrash = torch.empty(512 * 1024 * 1024, dtype=torch.uint8, device="cuda") if os.environ.get("PROBE_THRASH") == "1" else None
+
+
 def timed(fn):
+    if _thrash is not None:  # what another rank's phase does to the caches when W handles share one GPU
+        _thrash.fill_(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = fn()
@@ -106,6 +111,17 @@ for W in Ws:
         _, t = timed(lambda: (single.step_many(dt, 5), single.sync()))
         row["plain_single_handle_ms_per_step"] = round(t / 5, 3)
         single.close()
+    if os.environ.get("PROBE_OWN_ONLY") == "1" and W > 1:
+        # the same bodies rank 0 owns, alone in a plain handle: what its walk costs WITHOUT the other ranks' pieces
+        ids0, p0, v0 = E[0].owned_state()
+        alone = HIPBarnesHutSimulation(p0, v0, m[ids0], G, eps, 1.0, theta)
+        alone.step_many(dt, 2); alone.sync()
+        alone.enable_timers(True); alone.timers(reset=True)
+        alone.step_many(dt, 5); alone.sync()
+        tm = alone.timers(reset=True)
+        row["rank0_bodies_alone_walk_ms"] = round(tm["walk_ms"] / max(1, tm["steps"]), 3)
+        row["rank0_bodies_alone_nodes"] = alone.tree_stats(depth=False)["num_nodes"]
+        alone.close()
     print(json.dumps(row), flush=True)
     for e in E:
         e.sim.close()
