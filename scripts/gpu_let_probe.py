@@ -42,7 +42,7 @@ for W in Ws:
     np.random.seed(42)
     # PROBE_SCALE_RADIUS=0: the radius bench.py uses for every N (denser system); default: constant density
     R = 800.0 * (W ** (1 / 3) if os.environ.get("PROBE_SCALE_RADIUS", "1") != "0" else 1.0)
-    p, v, m = generate_distribution("galaxy", n, R, G)
+    p, v, m = generate_distribution(os.environ.get("PROBE_DIST", "galaxy"), n, R, G)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
         E = [HipLetEngine(p, v, m, G, eps, 1.0, theta, 0, r, W) for r in range(W)]
