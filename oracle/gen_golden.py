@@ -514,6 +514,11 @@ if __name__ == "__main__":
         print(f"[gen_golden] {name}", flush=True)
         fn(a)
         print(f"[gen_golden] {name} done in {time.time() - t0:.1f}s", flush=True)
-    with open(os.path.join(GOLD, "MANIFEST.json"), "w") as f:
-        json.dump({fn_: os.path.getsize(os.path.join(GOLD, fn_)) for fn_ in sorted(os.listdir(GOLD))
-                   if fn_.endswith(".npz")}, f, indent=1)
+    man_path = os.path.join(GOLD, "MANIFEST.json")
+    keep = {}
+    if os.path.exists(man_path):  # "oracle_cache": hashes of tests/cache/* (scripts/oracle_cache.py) - not ours to drop
+        with open(man_path) as f:
+            keep = {k: v for k, v in json.load(f).items() if k == "oracle_cache"}
+    with open(man_path, "w") as f:
+        json.dump({**{fn_: os.path.getsize(os.path.join(GOLD, fn_)) for fn_ in sorted(os.listdir(GOLD))
+                      if fn_.endswith(".npz")}, **keep}, f, indent=1, sort_keys=True)
