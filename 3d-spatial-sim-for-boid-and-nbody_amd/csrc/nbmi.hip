@@ -125,9 +125,14 @@ struct TreeInfo {
     // of 10 is still there when the host looks (nbmi_sync / getters), which reports and clears it.
     int sticky_error;
     long long sticky_nodes;  // num_nodes of the build that overflowed
-    // force precision "auto": 1 when more than half of the last walk's waves chose float64 - then every wave does
-    // (k_flag_share; outside the ranges the per-step header reset clears)
+    // force precision "auto": 1 while most of the system asks for float64 - then every wave computes in it.  Entered
+    // when more than half of the step's waves ask, left when fewer than 40 % do (hysteresis [r4]: a system hovering at
+    // one half must not flip the whole walk between the two loops step by step).  Decided by k_scan_subtiles from
+    // (ask_waves, n_waves) of the handle's own bodies; in owner mode with several ranks the host sums the ranks'
+    // votes and sets the verdict for all of them (nbmi_owner_set_all64) - one system, one decision, whatever the
+    // world size.  Outside the ranges the per-step header reset clears: the value of the last step is the state.
     int force_all64;
+    int ask_waves, n_waves;  // this build's votes: waves whose own density asked for float64 / waves
     int pad1;
     // owner mode [r3]: the own tree in its global form (k_chain_fix) - how many of its first nodes are copies of cells
     // that begin on a lower rank (not walked, not exported), and where the walk array begins behind the jump node
@@ -545,6 +550,12 @@ __device__ __forceinline__ dd dd_shfl_up(const dd &v, int d) { return dd{__shfl_
 __device__ __forceinline__ SubVal sub_shfl_up(const SubVal &v, int d) {
     return SubVal{dd_shfl_up(v.m, d), dd_shfl_up(v.x, d), dd_shfl_up(v.y, d), dd_shfl_up(v.z, d), __shfl_up(v.c, d)};
 }
+// the system-wide half of force precision "auto" (TreeInfo::force_all64): enter above 50 % of the waves, leave below 40 %
+__host__ __device__ inline int all64_rule(int prev, long long ask, long long waves) {
+    return prev ? (10 * ask >= 4 * waves ? 1 : 0) : (2 * ask > waves ? 1 : 0);
+}
+__global__ void k_set_all64(TreeInfo *info, int v) { info->force_all64 = v; }
+
 __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4 *__restrict__ sub_tot,
                                                                    const int32_t *__restrict__ sub_cnt, int64_t nsub,
                                                                    Moment *__restrict__ T, int32_t *__restrict__ subPex,
@@ -582,7 +593,9 @@ __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4
     if (sub_flag && t == 0) {
         long long tot = 0;
         for (int q = 0; q < kSubScanThreads / 64; q++) tot += fsum[q];
-        info->force_all64 = 2 * tot > nwaves ? 1 : 0;
+        info->ask_waves = (int)tot;
+        info->n_waves = (int)nwaves;
+        info->force_all64 = all64_rule(info->force_all64, tot, nwaves);
     }
     SubVal off = sub_zero();
     for (int q = 0; q < w; q++) off = sub_add(off, wsum[q]);
@@ -3137,6 +3150,7 @@ struct nbmi_sim {
     unsigned char *wave_flag = nullptr;  // device [one per wave]
     int32_t *sub_flag = nullptr;         // device [one per tile]: waves of the tile that ask for float64
     double step_dt = 0.0;                // dt of the step being enqueued (0: a build without a step)
+    int owner_all64 = -1;                // owner mode: the system-wide "every wave float64" verdict for the next walk (-1: this rank's own rule)
     double owner_dt = 0.0;               // owner mode: the dt the next nbmi_owner_step will use (nbmi_owner_set_dt; "auto" needs it at build time)
     int balance_blocks = 0;           // the block count the bounds on the device were made for (0: none yet)
     // the cuts for the NEXT walk are made on a stream of their own, beside the next step's build (one workgroup, 70 us
@@ -4360,11 +4374,32 @@ int nbmi_owner_export_let(nbmi_sim *s, const void *dev_boxes, const void *dev_ch
     return 0;
 }
 
+int nbmi_owner_step_facts(nbmi_sim *s, int64_t *out4) {
+    if (int rc = owner_check(s, "nbmi_owner_step_facts")) return rc;
+    if (!out4) { nbmi::set_error("nbmi_owner_step_facts: null output"); return NBMI_ERR_ARG; }
+    out4[0] = out4[1] = 0;
+    out4[2] = out4[3] = (int64_t)1 << 62;
+    if (s->n == 0 || s->world == 1 || !s->h_info) return 0;
+    NBMI_HIP_CHECK(hipEventSynchronize(s->ev_info));  // (long complete: nbmi_owner_export_let waited behind it)
+    const TreeInfo &h = *s->h_info;
+    if (s->force_prec == 0 && s->nodesd && s->owner_dt > 0.0) { out4[0] = h.ask_waves; out4[1] = h.n_waves; }
+    out4[2] = s->own_base + h.own_skip - 1;                        // tree rows that fit in front of the own piece
+    out4[3] = s->node_capacity - (s->own_base + h.num_nodes) - 1;  // ... and behind it
+    return 0;
+}
+
+int nbmi_owner_set_all64(nbmi_sim *s, int verdict) {
+    if (int rc = owner_check(s, "nbmi_owner_set_all64")) return rc;
+    s->owner_all64 = verdict < 0 ? -1 : (verdict ? 1 : 0);
+    return 0;
+}
+
 int nbmi_owner_step(nbmi_sim *s, const void *dev_recv, const int64_t *counts, double dt) {
     if (int rc = owner_check(s, "nbmi_owner_step")) return rc;
     if (!counts || (s->world > 1 && !dev_recv)) { nbmi::set_error("nbmi_owner_step: null buffer"); return NBMI_ERR_ARG; }
     if (s->n == 0) return 0;
     hipStream_t st = s->stream;
+    if (s->owner_all64 >= 0) k_set_all64<<<1, 1, 0, st>>>(s->info, s->owner_all64);  // the ranks' common verdict
     if (s->world == 1) {  // nothing received: the walk array is the own tree; an overflow freezes the walk and is reported at the next sync
         k_let_finish_alone<<<1, 1, 0, st>>>(s->info);
         NBMI_HIP_CHECK(hipGetLastError());

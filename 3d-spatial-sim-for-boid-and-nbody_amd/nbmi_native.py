@@ -60,6 +60,8 @@ PROTOTYPES = {
     "nbmi_owner_chain_doubles": (C.c_int, []),
     "nbmi_owner_export_let": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "nbmi_owner_step": (C.c_int, [_vp, _vp, _vp, _dbl]),
+    "nbmi_owner_step_facts": (C.c_int, [_vp, _vp]),
+    "nbmi_owner_set_all64": (C.c_int, [_vp, C.c_int]),
     "nbmi_visible_points": (C.c_int, [_vp, _vp, _dbl, _dbl, _dbl, _vp, _vp, _i64, _vp]),
     "nbmi_set_exchange_sync": (C.c_int, [_vp, C.c_int]),
     "nbmi_set_force_precision": (C.c_int, [_vp, C.c_int, _dbl]),

@@ -407,6 +407,18 @@ class HIPOwnerSimulation(HIPBarnesHutSimulation):
     def let_row_bytes(self):
         return int(self._lib.nbmi_owner_let_row_bytes())
 
+    def owner_step_facts(self):
+        """After owner_export_let: int64[4] = (waves asking for float64 forces, waves, tree rows that fit in front of /
+        behind the own piece of the walk array)."""
+        out = np.zeros(4, dtype=np.int64)
+        _nat.check(self._lib.nbmi_owner_step_facts(self._h, _nat.ptr(out)), "nbmi_owner_step_facts")
+        return out
+
+    def owner_set_all64(self, verdict):
+        """The ranks' common decision for the next owner_step: True / False = every wave float64 / the waves decide;
+        None = this rank's own rule."""
+        _nat.check(self._lib.nbmi_owner_set_all64(self._h, -1 if verdict is None else int(bool(verdict))), "nbmi_owner_set_all64")
+
     def owner_step(self, dev_lets, counts, dt):
         counts = np.ascontiguousarray(counts, dtype=np.int64)
         _nat.check(self._lib.nbmi_owner_step(self._h, int(dev_lets), _nat.ptr(counts), float(dt)), "nbmi_owner_step")

@@ -258,7 +258,12 @@ class HipLetEngine:
     def op_export_let(self):
         return self.sim.owner_export_let(self.boxes.data_ptr(), self.chains.data_ptr(), self.let_send.data_ptr())
 
-    def op_step(self, recv_counts, dt):
+    def step_facts(self):
+        """(asking waves, waves, tree rows that fit in front of / behind the own piece): see nbmi_owner_step_facts."""
+        return self.sim.owner_step_facts()
+
+    def op_step(self, recv_counts, dt, all64=None):
+        self.sim.owner_set_all64(all64)
         self.sim.owner_step(self.let_recv.data_ptr(), recv_counts, dt)
 
     def wait(self):
@@ -288,6 +293,8 @@ class LetBarnesHut:
         self.engine, self.rank, self.world = engine, rank, world
         self.comm = comm
         self.n = engine.n_total
+        self.all64 = False  # force precision "auto": the system-wide "every wave float64" state (hysteresis, see _verdict)
+        self._carried = None  # a failure of the last op_step, to be raised by every rank at the next exchange
         if world > 1 and comm is None:
             raise ValueError("LetBarnesHut over more than one rank needs a communicator")
 
@@ -314,10 +321,18 @@ class LetBarnesHut:
             return
         bad = np.nonzero(extras[:, col])[0]
         if len(bad):
+            if isinstance(phase, dict):  # the flag's value says where that rank failed
+                phase = phase.get(int(extras[bad[0], col]), "?")
             msg = f"owner mode: rank(s) {bad.tolist()} failed in the {phase} phase (every rank raises this together)"
             if failed is not None:
                 raise RuntimeError(f"{msg}: {failed}") from failed
             raise RuntimeError(msg)
+
+    def _verdict(self, ask, waves):
+        """The single handle's rule on the ranks' summed votes (nbmi.hip all64_rule): entered when more than half of
+        the system's waves ask for float64 forces, left when fewer than 40 % do."""
+        self.all64 = (10 * ask >= 4 * waves) if self.all64 else (2 * ask > waves)
+        return self.all64
 
     def _step(self, dt, substeps):
         e, W = self.engine, self.world
@@ -339,19 +354,22 @@ class LetBarnesHut:
                 allsamp = e.all_samples
             # A failure inside one rank's library call (the tree of the last step overflowed, a sort timed out ...) is
             # carried through the next exchange of counts as a flag: every rank raises, none is left in a collective
-            failed = None
+            failed, self._carried = self._carried, None
+            where = 2 if failed is not None else 0
             try:
                 send_counts = e.op_partition(allsamp)  # rows of the bodies that leave, grouped by destination
+                if failed is not None:
+                    send_counts = np.zeros(W, dtype=np.int64)
             except RuntimeError as exc:
                 if W == 1:
                     raise
-                failed, send_counts = exc, np.zeros(W, dtype=np.int64)
+                failed, send_counts, where = exc, np.zeros(W, dtype=np.int64), 1
             n_recv = 0
             if W > 1:
                 held = e.sim.n if hasattr(e, "sim") else 0  # (a stand-in engine has no row budget: 0 rows of "infinity")
                 room = e.cap if hasattr(e, "sim") else (1 << 62)
-                recv_counts, M, ex = self._exchange_counts(send_counts, [held, room, 1 if failed else 0])
-                self._raise_together(failed, ex, 2, "partition")
+                recv_counts, M, ex = self._exchange_counts(send_counts, [held, room, where])
+                self._raise_together(failed, ex, 2, {1: "partition", 2: "walk (of the previous step)"})
                 if M is not None:
                     # every rank checks EVERY rank's body rows against THAT rank's budget and raises with it
                     after = ex[:, 0] + M.sum(axis=0)  # rows a rank holds while it adopts: stayers, leavers' rows, arrivals
@@ -364,33 +382,65 @@ class LetBarnesHut:
                 e.wait()
                 wire += int(send_counts.sum()) * ROW * 8
             rows, n_new = e.recv_rows, n_recv
-            e.op_adopt(rows, n_new)
+            try:
+                e.op_adopt(rows, n_new)
+            except RuntimeError as exc:  # (travels with the tree counts below: every rank raises)
+                if W == 1:
+                    raise
+                failed, where = exc, 2
             counts = np.zeros(W, dtype=np.int64)
+            all64 = None
             if W > 1:
                 self.comm.all_gather(e.boxes, e.bbox)
                 if hasattr(e, "chain"):
                     self.comm.all_gather(e.chains, e.chain)
                     wire += e.chain.numel() * 8
                 e.wait()
-                try:
-                    let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
-                except RuntimeError as exc:
-                    failed, let_counts = exc, np.zeros(W, dtype=np.int64)
+                let_counts = np.zeros(W, dtype=np.int64)
+                facts = np.array([0, 0, 1 << 62, 1 << 62], dtype=np.int64)
+                if failed is None:
+                    try:
+                        let_counts = e.op_export_let()  # rows for every other rank: only what THAT rank's bodies can open
+                        if hasattr(e, "step_facts"):
+                            facts = np.asarray(e.step_facts(), dtype=np.int64)
+                    except RuntimeError as exc:
+                        failed, let_counts, where = exc, np.zeros(W, dtype=np.int64), 1
                 room = e.let_recv.shape[0]
-                counts, M, ex = self._exchange_counts(let_counts, [room, 1 if failed else 0])
-                self._raise_together(failed, ex, 1, "tree export")
+                counts, M, ex = self._exchange_counts(let_counts, [room, where if failed else 0, *facts.tolist()])
+                self._raise_together(failed, ex, 1, {1: "tree export", 2: "adopt"})
                 if M is not None:  # the same verdict on every rank
                     incoming = M.sum(axis=0)
                     if (incoming > ex[:, 0]).any():
                         j = int(np.argmax(incoming - ex[:, 0]))
                         raise RuntimeError(f"owner mode: rank {j} would receive {int(incoming[j])} tree rows, {int(ex[j, 0])} "
                                            "reserved (every rank raises this together)")
+                    # ... and whether the pieces fit around every rank's own tree (nbmi_owner_step's own check, which
+                    # would fire on that rank alone): rows from lower ranks go in front of it, from higher ranks behind
+                    lower = np.array([M[:j, j].sum() for j in range(W)])
+                    upper = np.array([M[j + 1:, j].sum() for j in range(W)])
+                    if (lower > ex[:, 4]).any() or (upper > ex[:, 5]).any():
+                        j = int(np.argmax(np.maximum(lower - ex[:, 4], upper - ex[:, 5])))
+                        raise RuntimeError(f"owner mode: the trees rank {j} receives do not fit around its own ({int(lower[j])} rows "
+                                           f"in front, room {int(ex[j, 4])}; {int(upper[j])} behind, room {int(ex[j, 5])}; every "
+                                           "rank raises this together)")
+                    # force precision "auto": ONE decision for the system from the ranks' summed votes [r4] - a rank
+                    # that applied the rule to its own waves made the arithmetic depend on the world size
+                    if int(ex[:, 3].sum()) > 0:
+                        all64 = self._verdict(int(ex[:, 2].sum()), int(ex[:, 3].sum()))
                 elif int(counts.sum()) > room:
                     raise RuntimeError(f"rank {self.rank}: {int(counts.sum())} received tree rows exceed the {room} reserved")
                 self.comm.all_to_all_rows(e.let_recv, e.let_send, counts, let_counts)
                 e.wait()
                 wire += e.bbox.numel() * 8 + int(let_counts.sum()) * e.LET_ROW_BYTES
-            e.op_step(counts, dt)
+            try:
+                if all64 is None:
+                    e.op_step(counts, dt)
+                else:
+                    e.op_step(counts, dt, all64=all64)
+            except RuntimeError as exc:
+                if W == 1:
+                    raise
+                self._carried = exc  # (what can fail on one rank alone now: a device error; raised by all next time)
             e.let_counts = counts
             e.wire_bytes = wire
             e.migrated = int(send_counts.sum())

@@ -18,6 +18,7 @@ not installed in this image); without it the .zstd functions raise and raw .npz 
 """
 import ctypes as C
 import json
+import os
 import struct
 import time
 from datetime import datetime
@@ -122,9 +123,31 @@ def find_latest_state(rec_dir: Path, max_frame: int):
 
 
 # ---- frames (reference :88-210, :231-326) -----------------------------------------------------
+def _atomically(path: Path, write):
+    """`write(file object)` into a temporary name beside `path`, then os.replace: a frame or state file either exists
+    complete or not at all.  An interrupt in the middle of a 24 MB frame write (a large share of a frame interval at
+    1 M bodies) must not leave a truncated file that get_completed_frames() counts and a resume builds on."""
+    path = Path(path)
+    tmp = path.with_name("." + path.name + ".part")
+    try:
+        with open(tmp, "wb") as f:
+            write(f)
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            tmp.unlink()
+        except OSError:
+            pass
+        raise
+
+
+def write_bytes_atomic(path: Path, blob: bytes):
+    _atomically(path, lambda f: f.write(blob))
+
+
 def save_frame(rec_dir: Path, frame_idx: int, positions: np.ndarray, colors: np.ndarray):
-    np.savez(Path(rec_dir) / f"frame_{frame_idx:04d}.npz", positions=positions.astype(np.float32),
-             colors=colors.astype(np.float32))
+    p32, c32 = positions.astype(np.float32), colors.astype(np.float32)
+    _atomically(Path(rec_dir) / f"frame_{frame_idx:04d}.npz", lambda f: np.savez(f, positions=p32, colors=c32))
 
 
 def delta_quantize(cur: np.ndarray, prev: np.ndarray) -> np.ndarray:
@@ -232,7 +255,7 @@ def compress_recording(rec_dir: Path, upto: int = None, batch_size: int = COMPRE
         with np.load(nf) as d:
             cur = (d["positions"].copy(), d["colors"].copy())
         blob = compress_frame(cur[0], cur[1], *(prev or (None, None)))
-        zf.write_bytes(blob)
+        write_bytes_atomic(zf, blob)
         nf.unlink()
         # the decoder sees the quantised frame: chain on what it will reconstruct
         prev = decompress_frame(blob, *(prev or (None, None)))
@@ -319,23 +342,23 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
             zf, _ = _frame_paths(rec_dir, frame)
             if frame == 0:
                 p32, c32 = gpu_sim.frame_keyframe()
-                zf.write_bytes(pack_container(1, p32.tobytes(), c32.tobytes()))
+                write_bytes_atomic(zf, pack_container(1, p32.tobytes(), c32.tobytes()))
             else:
                 dp, dc = gpu_sim.frame_delta()
-                zf.write_bytes(pack_container(2, dp.tobytes(), dc.tobytes()))
+                write_bytes_atomic(zf, pack_container(2, dp.tobytes(), dc.tobytes()))
         else:
             save_frame(rec_dir, frame, gpu_sim.get_positions(), gpu_sim.get_colors())
 
     def write_state(frame, compressed=False):
-        (np.savez_compressed if compressed else np.savez)(
-            rec_dir / f"state_{frame:04d}.npz", positions=gpu_sim.get_positions_f64(),
-            velocities=gpu_sim.get_velocities(), masses=masses)
+        x, v = gpu_sim.get_positions_f64(), gpu_sim.get_velocities()
+        _atomically(rec_dir / f"state_{frame:04d}.npz",
+                    lambda f: (np.savez_compressed if compressed else np.savez)(f, positions=x, velocities=v, masses=masses))
 
     def write_keyframe(frame):  # a frame that does not depend on the delta chain (format 1 is legal anywhere)
         gpu_sim.compute_colors(15.0)
         zf, _ = _frame_paths(rec_dir, frame)
         p32, c32 = gpu_sim.frame_keyframe()
-        zf.write_bytes(pack_container(1, p32.tobytes(), c32.tobytes()))
+        write_bytes_atomic(zf, pack_container(1, p32.tobytes(), c32.tobytes()))
 
     frame = start_frame - 1
     try:
@@ -356,8 +379,9 @@ def record(config: dict, resume: bool = False, root: Path = None, quiet: bool = 
         if at >= 0:
             on_disk = any(q.exists() for q in _frame_paths(rec_dir, at))
             if at == frame and not on_disk:
-                # stepped, frame not written (or its write was cut short: the device-side delta chain may already
-                # have moved on, so this frame is written absolute)
+                # stepped, frame not written - or its write was cut short: frames reach their name only complete
+                # (_atomically), so a cut-short write left nothing; the device-side delta chain may already have
+                # moved on, so this frame is written absolute
                 write_keyframe(at) if direct_zstd else write_frame(at)
             write_state(at, compressed=True)
         say(f"\n[Record] Paused at frame {at}; resume with record(config, resume=True)")

@@ -478,17 +478,15 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": ("f64 pair forces for the waves of 64 bodies whose densest quarter has G*rho*dt^2 > 5e-5 - and for every wave "
-                  "once more than half of them qualify (library default 'auto') -, f32 pair forces with f64 sums for the "
-                  "others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
+        "dtype": ("f64 pair forces for the waves of 64 bodies whose densest quarter has G*rho*dt^2 > tau - and for every wave "
+                  "while most of the system qualifies (entered above 50 % of the waves, left below 40 %; library default "
+                  "'auto') -, f32 pair forces with f64 sums for the others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
                  else "f32 pair forces, f64 sums/state",
         "data": "synthetic (reference IC generator restated, seed 42)",
         "config": {"workload": workload, "distribution": dist_name.replace("_fast", ""),
                    "bodies_per_gpu": n_total // world if strong else per_gpu, "bodies_total": n_total,
                    "theta": theta, "dt": dt, "G": G, "softening": eps, "spawn_radius": R, "method": method,
-                   # owner mode ("let") has no float64 node records yet: fp32 forces there
-                   "force_precision": None if method != "barnes_hut" else
-                                      ("f32" if (use_dist and shard_mode == "let") else (args.force_precision or "auto")),
+                   "force_precision": None if method != "barnes_hut" else (args.force_precision or "auto"),
                    "parallelism": par},
     }
 
@@ -496,8 +494,11 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         out["config"]["owner_mode_check"] = mode_check
     if use_dist and method == "barnes_hut" and shard_mode == "let" and rank == 0:
         e = sharded.engine
+        share, all64 = sim.force_precision_share()
         out["exchange"] = {"bytes_sent_per_step_rank0": int(e.wire_bytes), "bodies_migrated_last_step_rank0": int(e.migrated),
-                           "received_tree_rows_rank0": [int(c) for c in e.let_counts], "owned_bodies_rank0": int(sim.n)}
+                           "received_tree_rows_rank0": [int(c) for c in e.let_counts], "owned_bodies_rank0": int(sim.n),
+                           # rank 0's own waves that asked for float64 forces; whether the SYSTEM-WIDE vote made every wave float64
+                           "float64_wave_share_rank0": round(float(share), 4), "all_waves_float64": bool(all64)}
     if world == 1 and rank == 0 and not use_dist:
         # second pass with per-phase HIP events on the library stream (same K steps)
         sim.enable_timers(True)

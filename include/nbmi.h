@@ -203,8 +203,13 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * "auto") - the exchanged rows carry the float64 centre of mass and G m of every node, and the receiver builds
  * both walk records from them.  "auto" is decided while nbmi_owner_adopt builds the tree, so the dt of the
  * step has to be known by then: nbmi_owner_set_dt(h, dt) before nbmi_owner_adopt (no dt set: fp32 forces, as
- * "auto" does for any build that is not part of a step).  Each rank decides for its own waves, and applies the
- * "more than half of the waves" rule to its own bodies.
+ * "auto" does for any build that is not part of a step).  Each rank decides for its own waves by their density;
+ * the "most of the system asks => every wave" half of the rule is taken SYSTEM-WIDE [r4]: after
+ * nbmi_owner_export_let, nbmi_owner_step_facts gives the rank's votes (asking waves, waves), the caller sums them
+ * over the ranks (they ride in the exchange of the tree counts), applies the single handle's rule (enter above 50 %,
+ * leave below 40 %) and hands the verdict to every rank with nbmi_owner_set_all64 before nbmi_owner_step - the
+ * arithmetic no longer depends on the world size or on where the splitters fall.  Without a verdict (-1, default) a
+ * rank applies the rule to its own waves.
  *
  * Getters of an owner handle return the owned bodies in their current (key) order; nbmi_owner_get_ids gives the
  * global body ids of those rows. */
@@ -225,6 +230,15 @@ int nbmi_owner_adopt(nbmi_sim *sim, const void *dev_recv_rows, int64_t n_recv, c
                      void *dev_chain);
 int nbmi_owner_export_let(nbmi_sim *sim, const void *dev_boxes, const void *dev_chains, void *dev_let, int64_t *counts_host);
 int nbmi_owner_step(nbmi_sim *sim, const void *dev_recv_let, const int64_t *recv_counts_host, double dt);
+/* After nbmi_owner_export_let: out4 = {waves of this rank whose own density asks for float64 forces, waves of this
+ * rank (both 0 unless the mode is "auto" and a dt is set), tree rows that still fit in front of the own piece of the
+ * walk array, tree rows that fit behind it} - what every rank needs to know of every other rank to take the
+ * system-wide precision decision and to evaluate nbmi_owner_step's "received trees do not fit" for all ranks
+ * together (a rank raising alone leaves the others in the next collective). */
+int nbmi_owner_step_facts(nbmi_sim *sim, int64_t *out4_host);
+/* verdict 1 / 0: the next nbmi_owner_step computes every wave's forces in float64 / leaves the choice to the waves;
+ * -1: back to the rank's own rule. */
+int nbmi_owner_set_all64(nbmi_sim *sim, int verdict);
 
 /* Render-side reduction: NBodySimulation._compute_visibility + the gather of
  * draw() on the device (nbody/simulation.py:880-903, 927-928).  Frustum test of
@@ -243,8 +257,8 @@ int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
 /* Arithmetic of the Barnes-Hut pair forces (the accepted (body, node) sets are the reference's in every mode):
  *   0  per wave of 64 key-adjacent bodies: float64 where G rho dt^2 of the wave's densest quarter (16 bodies: sum of
  *      G m over the volume of their bounding box, every edge at least one softening length) exceeds `tau`
- *      (default 5e-5; tau = 0 keeps the current value), fp32 elsewhere - and float64 for EVERY wave of a step in
- *      which more than half of the waves qualify.  Default.  The reference computes in float64 throughout
+ *      (default 5e-5; tau = 0 keeps the current value), fp32 elsewhere - and float64 for EVERY wave while most of
+ *      the system qualifies (entered when more than half of a step's waves do, left below 40 %).  Default.  The reference computes in float64 throughout
  *      (nbody/simulation.py:246-268); in the dense part of a system fp32's systematic roundings are amplified to
  *      > 1e-4 of the largest coordinate within 100 steps, and where most of the system is that dense the rest
  *      follows.

@@ -609,27 +609,11 @@ def _oracle_galaxy_1m(oracle, steps, keep):
 
 
 def _oracle_galaxy_1m_compute(oracle, steps, keep):
-    """Oracle positions of BASELINE config 2 after the steps in `keep`: from tests/cache/ (scripts/oracle_traj_cache.py,
-    same strict-IEEE build: bit-identical on any x86 host) when the files travelled with the tree, else computed here
-    (about 2.3 s per step on 32 host threads)."""
-    import os
-    from conftest import ROOT
-    from tools.presets import generate_distribution
-    np.random.seed(42)
-    p, v, m = generate_distribution("galaxy", 1_000_000, 800.0, 0.07)
-    files = {k: os.path.join(ROOT, "tests", "cache", f"oracle_galaxy_1000000_step{k}.npy") for k in keep}
-    if all(os.path.exists(f) for f in files.values()):
-        print("  (oracle trajectory from tests/cache)")
-        return p, v, m, {k: np.load(f) for k, f in files.items()}
-    L = oracle.lib()
-    L.nbref_set_num_threads(min(32, int(L.nbref_num_threads())))
-    ostep = oracle.BHStepper(p, v, m, 0.5, 0.07, 1.5, 1.0, cap=oracle.UNCAPPED, fast=False)
-    out = {}
-    for k in range(1, steps + 1):
-        ostep.step(0.05)
-        if k in keep:
-            out[k] = ostep.pos.copy()
-    return p, v, m, out
+    """Oracle positions of BASELINE config 2 after the steps in `keep` (tests/oracle_cases.py: from tests/cache/ when the
+    files travelled with the tree AND their SHA-256 is the committed one, else computed here - about 2.3 s per step on
+    32 host threads - and checked against the same hashes)."""
+    import oracle_cases
+    return oracle_cases.load("galaxy_1m", tuple(keep), oracle)
 
 
 def test_galaxy_1m_100_steps_meets_the_north_star_bound(gpu, oracle):

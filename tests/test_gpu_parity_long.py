@@ -1,0 +1,88 @@
+"""north_star's accuracy clause under the driver's eyes: <= 1e-4 of the largest coordinate after
+100 steps, in the DEFAULT force precision,
+
+  (a) at north_star's own size - BASELINE config 4's input, the 10 M-body collision at dt 0.25 - on one handle and
+      owned by eight ranks, against the uncapped oracle's every-16th-body snapshot;
+  (b) at 1 M bodies on inputs the "auto" precision heuristic was NOT tuned on (tau was read off config 2, seed 42):
+      another galaxy seed, a collision with config 4's constants, a Plummer cluster through the Barnes-Hut path.
+
+Oracle trajectories: tests/oracle_cases.py (tests/cache/*.npy made by scripts/oracle_cache.py in the build container,
+SHA-256 of every file committed in tests/golden/MANIFEST.json and asserted on load; a missing 1 M file is computed
+on the spot, a missing 10 M file skips with the reason).  Reference arithmetic: float64 throughout
+(/root/reference/nbody/simulation.py:246-268)."""
+import numpy as np
+import pytest
+
+import oracle_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _errors(x, ref):
+    d = np.abs(x - ref).max(axis=1) / np.abs(ref).max()
+    return float(d.max()), float(np.quantile(d, 0.999)), float(np.sqrt((d ** 2).mean()))
+
+
+@pytest.mark.parametrize("case", ["galaxy_1m_seed7", "collision_1m", "cluster_1m"])
+def test_held_out_1m_inputs_100_steps_default_precision(gpu, oracle, case):
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    c = oracle_cases.CASES[case]
+    p, v, m, ref = oracle_cases.load(case, (50, 100), oracle)
+    sim = HIPBarnesHutSimulation(p, v, m, c["G"], c["eps"], 1.0, c["theta"])
+    shares = []
+    for k in range(1, 101):
+        sim.step(c["dt"])
+        if k in (1, 50, 100):
+            shares.append(sim.force_precision_share())
+        if k in ref:
+            mx, p999, rms = _errors(sim.get_positions_f64(), ref[k])
+            print(f"  {case} x {k} steps: max {mx:.3e} p99.9 {p999:.3e} rms {rms:.3e}; float64 wave share / all-float64 "
+                  f"at steps 1, 50, 100 so far: {[(round(s, 3), a) for s, a in shares]}")
+    assert sim.tree_stats()["num_nodes"] > c["n"]
+    assert mx <= 1e-4, "north_star: <= 1e-4 relative position error after 100 steps"
+    assert p999 <= 1e-5
+    sim.close()
+
+
+_IC_10M = {}
+
+
+def _collision_10m(oracle):
+    if "v" not in _IC_10M:
+        _IC_10M["v"] = oracle_cases.load("collision_10m", (100,), oracle, compute_if_missing=False)
+    return _IC_10M["v"]
+
+
+def test_collision_10m_100_steps_single_handle(gpu, oracle):
+    """north_star's size and config 4's constants (tools/presets.py:2424-2440) on one GPU, default precision."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    c = oracle_cases.CASES["collision_10m"]
+    p, v, m, ref = _collision_10m(oracle)
+    sim = HIPBarnesHutSimulation(p, v, m, c["G"], c["eps"], 1.0, c["theta"])
+    sim.step_many(c["dt"], 100)
+    mx, p999, rms = _errors(sim.get_positions_f64()[::c["every"]], ref[100])
+    print(f"  collision 10 M x 100 steps, one handle: max {mx:.3e} p99.9 {p999:.3e} rms {rms:.3e}; "
+          f"float64 share / all-float64 {sim.force_precision_share()}; nodes {sim.tree_stats()['num_nodes']}")
+    sim.close()
+    assert mx <= 1e-4 and p999 <= 1e-5
+
+
+def test_collision_10m_100_steps_eight_owner_ranks(gpu, oracle):
+    """Config 4 in its north_star form: the same input owned by eight key ranges (threads on one GPU through
+    LetBarnesHut.step itself), per-step exchange of the locally essential pieces of ONE global octree."""
+    from nbody.sharded import HipLetEngine, LetBarnesHut
+    from test_gpu_sharded_record import _ThreadComm, _run_ranks
+    c = oracle_cases.CASES["collision_10m"]
+    p, v, m, ref = _collision_10m(oracle)
+    world = 8
+    comm = _ThreadComm(world)
+    engines = [HipLetEngine(p, v, m, c["G"], c["eps"], 1.0, c["theta"], 0, r, world) for r in range(world)]
+    steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
+    out = _run_ranks(steppers, comm, c["dt"], 100)
+    mx, p999, rms = _errors(out[0][0][::c["every"]], ref[100])
+    print(f"  collision 10 M x 100 steps, 8 owner ranks: max {mx:.3e} p99.9 {p999:.3e} rms {rms:.3e}; owned "
+          f"{[int(e.sim.n) for e in engines]}; all-float64 {[int(e.sim.force_precision_share()[1]) for e in engines]}")
+    assert sum(e.sim.n for e in engines) == c["n"]
+    for e in engines:
+        e.sim.close()
+    assert mx <= 1e-4 and p999 <= 1e-5

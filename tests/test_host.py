@@ -261,3 +261,19 @@ def test_philox_known_answers():
         ctr = [int(v) for v in rng.randint(0, 2 ** 32, 4, dtype=np.uint64)]
         key = [int(v) for v in rng.randint(0, 2 ** 32, 2, dtype=np.uint64)]
         assert dev(ctr, key) == ref(ctr, key)
+
+
+def test_frames_reach_their_name_only_complete(tmp_path):
+    """tools.record._atomically: an interrupt inside the write leaves neither the file nor a partial one."""
+    from tools import record as rec
+    rec.save_frame(tmp_path, 0, np.zeros((5, 3)), np.ones((5, 3)))
+    assert rec.get_completed_frames(tmp_path) == 1
+
+    def dies(f):
+        f.write(b"half a frame")
+        raise KeyboardInterrupt
+
+    with pytest.raises(KeyboardInterrupt):
+        rec._atomically(tmp_path / "frame_0001.npz", dies)
+    assert rec.get_completed_frames(tmp_path) == 1
+    assert sorted(q.name for q in tmp_path.iterdir()) == ["frame_0000.npz"]
