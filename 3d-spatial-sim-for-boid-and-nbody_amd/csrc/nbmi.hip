@@ -125,9 +125,13 @@ struct TreeInfo {
     // of 10 is still there when the host looks (nbmi_sync / getters), which reports and clears it.
     int sticky_error;
     long long sticky_nodes;  // num_nodes of the build that overflowed
-    // force precision "auto": 1 while most of the system asks for float64 - then every wave computes in it.  Entered
-    // when more than half of the step's waves ask, left when fewer than 40 % do (hysteresis [r4]: a system hovering at
-    // one half must not flip the whole walk between the two loops step by step).  Decided by k_scan_subtiles from
+    // force precision "auto": 1 while a large part of the system asks for float64 - then every wave computes in it.
+    // Entered when more than a third of the step's waves ask, left when fewer than a quarter do (hysteresis: a system
+    // hovering at the threshold must not flip the whole walk between the two loops step by step).  [r4] Round 3
+    // entered above one half: the held-out 1 M collision at dt 0.25 (36 % of the waves asking at the start, 61 % after
+    // 100 steps) then ended at 3.1e-5 - 3 x inside the bound - where every wave in float64 ends at 2.5e-14 and costs
+    // nothing extra (the waves that ask are the ones that visit most nodes: with 48 % of them in float64 the walk
+    // already takes the all-float64 time; profiles/r04_precision_cases.jsonl).  Decided by k_scan_subtiles from
     // (ask_waves, n_waves) of the handle's own bodies; in owner mode with several ranks the host sums the ranks'
     // votes and sets the verdict for all of them (nbmi_owner_set_all64) - one system, one decision, whatever the
     // world size.  Outside the ranges the per-step header reset clears: the value of the last step is the state.
@@ -550,9 +554,11 @@ __device__ __forceinline__ dd dd_shfl_up(const dd &v, int d) { return dd{__shfl_
 __device__ __forceinline__ SubVal sub_shfl_up(const SubVal &v, int d) {
     return SubVal{dd_shfl_up(v.m, d), dd_shfl_up(v.x, d), dd_shfl_up(v.y, d), dd_shfl_up(v.z, d), __shfl_up(v.c, d)};
 }
-// the system-wide half of force precision "auto" (TreeInfo::force_all64): enter above 50 % of the waves, leave below 40 %
-__host__ __device__ inline int all64_rule(int prev, long long ask, long long waves) {
-    return prev ? (10 * ask >= 4 * waves ? 1 : 0) : (2 * ask > waves ? 1 : 0);
+// the system-wide half of force precision "auto" (TreeInfo::force_all64): enter above a third of the waves, leave below a quarter
+constexpr int kAll64Enter = 333, kAll64Leave = 250;
+// (thresholds in per mille of the waves: kAll64Enter / kAll64Leave; NBMI_ALL64_ENTER / NBMI_ALL64_LEAVE for experiments)
+__host__ __device__ inline int all64_rule(int prev, long long ask, long long waves, int enter_pm, int leave_pm) {
+    return prev ? (1000 * ask >= (long long)leave_pm * waves ? 1 : 0) : (1000 * ask > (long long)enter_pm * waves ? 1 : 0);
 }
 __global__ void k_set_all64(TreeInfo *info, int v) { info->force_all64 = v; }
 
@@ -560,7 +566,7 @@ __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4
                                                                    const int32_t *__restrict__ sub_cnt, int64_t nsub,
                                                                    Moment *__restrict__ T, int32_t *__restrict__ subPex,
                                                                    const int32_t *__restrict__ sub_flag, int64_t nwaves,
-                                                                   TreeInfo *info) {
+                                                                   int enter_pm, int leave_pm, TreeInfo *info) {
     __shared__ SubVal wsum[kSubScanThreads / 64];
     __shared__ long long fsum[kSubScanThreads / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4
         for (int q = 0; q < kSubScanThreads / 64; q++) tot += fsum[q];
         info->ask_waves = (int)tot;
         info->n_waves = (int)nwaves;
-        info->force_all64 = all64_rule(info->force_all64, tot, nwaves);
+        info->force_all64 = all64_rule(info->force_all64, tot, nwaves, enter_pm, leave_pm);
     }
     SubVal off = sub_zero();
     for (int q = 0; q < w; q++) off = sub_add(off, wsum[q]);
@@ -3097,6 +3103,7 @@ struct nbmi_sim {
     Node64 *nodes64 = nullptr;  // float64 twin rows of the internal cells (near-tie re-decision)
     NodeD *nodesd = nullptr;    // float64 node records of every node (waves that compute forces in float64)
     int force_prec = 0;         // 0 = per wave by local density, 1 = fp32 everywhere, 2 = float64 everywhere (NBMI_FORCE_PREC)
+    int all64_enter_pm = kAll64Enter, all64_leave_pm = kAll64Leave;  // "auto": every wave float64 while most of the system asks (per mille of the waves)
     double prec_tau = 5.0e-5;   // force_prec 0: float64 where G rho dt^2 exceeds this (NBMI_PREC_TAU)
     WalkTable *wtab = nullptr;  // device copy of the walk's per-handle constants
     uint8_t *node_level = nullptr;
@@ -3308,7 +3315,7 @@ int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
     // (delta, the in-sub-tile prefixes S / PexL and the sub-tile totals: written by k_gather_scan)
     const int64_t nsub = (n + 1 + kScanTile - 1) / kScanTile;  // sub-tiles that hold the entries 0 .. n
     k_scan_subtiles<<<1, kSubScanThreads, 0, st>>>(s->sub_tot, s->sub_cnt, nsub, s->T, s->subPex,
-                                                   auto_prec(s) ? s->sub_flag : nullptr, (n + 63) / 64, s->info);
+                                                   auto_prec(s) ? s->sub_flag : nullptr, (n + 63) / 64, s->all64_enter_pm, s->all64_leave_pm, s->info);
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     const int64_t ob = s->own_base;  // (owner mode: the own tree begins at this row of the walk array; node_level / node_ref / diag64 count from the tree's start)
@@ -3564,6 +3571,8 @@ static void read_env_knobs(nbmi_sim *s) {
         if (v >= 0 && v <= 2) s->force_prec = v;
     }
     if (const char *e = getenv("NBMI_PREC_TAU")) s->prec_tau = atof(e);
+    if (const char *e = getenv("NBMI_ALL64_ENTER")) s->all64_enter_pm = (int)(1000.0 * atof(e) + 0.5);
+    if (const char *e = getenv("NBMI_ALL64_LEAVE")) s->all64_leave_pm = (int)(1000.0 * atof(e) + 0.5);
     if (const char *e = getenv("NBMI_PREC")) s->prec = atoi(e);
     if (const char *e = getenv("NBMI_PREC_NEAR")) s->prec_near = atof(e);
     if (const char *e = getenv("NBMI_SORT_BITS")) {

@@ -35,6 +35,7 @@ import os
 import numpy as np
 
 ROW = 8  # doubles per packed body row (include/nbmi.h nbmi_export_shard)
+ALL64_ENTER, ALL64_LEAVE = 0.333, 0.25  # csrc/nbmi.hip kAll64Enter / kAll64Leave (per mille there)
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -329,9 +330,11 @@ class LetBarnesHut:
             raise RuntimeError(msg)
 
     def _verdict(self, ask, waves):
-        """The single handle's rule on the ranks' summed votes (nbmi.hip all64_rule): entered when more than half of
-        the system's waves ask for float64 forces, left when fewer than 40 % do."""
-        self.all64 = (10 * ask >= 4 * waves) if self.all64 else (2 * ask > waves)
+        """The single handle's rule on the ranks' summed votes (nbmi.hip all64_rule): every wave computes in float64
+        from the step in which more than a third of the system's waves ask for it until fewer than a quarter do."""
+        enter = float(os.environ.get("NBMI_ALL64_ENTER", ALL64_ENTER))
+        leave = float(os.environ.get("NBMI_ALL64_LEAVE", ALL64_LEAVE))
+        self.all64 = (ask >= leave * waves) if self.all64 else (ask > enter * waves)
         return self.all64
 
     def _step(self, dt, substeps):

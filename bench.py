@@ -479,7 +479,7 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": ("f64 pair forces for the waves of 64 bodies whose densest quarter has G*rho*dt^2 > tau - and for every wave "
-                  "while most of the system qualifies (entered above 50 % of the waves, left below 40 %; library default "
+                  "while most of the system qualifies (entered above a third of the waves, left below a quarter; library default "
                   "'auto') -, f32 pair forces with f64 sums for the others; f64 opening-test ties, f64 state/keys") if method == "barnes_hut"
                  else "f32 pair forces, f64 sums/state",
         "data": "synthetic (reference IC generator restated, seed 42)",

@@ -206,8 +206,8 @@ int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_
  * "auto" does for any build that is not part of a step).  Each rank decides for its own waves by their density;
  * the "most of the system asks => every wave" half of the rule is taken SYSTEM-WIDE [r4]: after
  * nbmi_owner_export_let, nbmi_owner_step_facts gives the rank's votes (asking waves, waves), the caller sums them
- * over the ranks (they ride in the exchange of the tree counts), applies the single handle's rule (enter above 50 %,
- * leave below 40 %) and hands the verdict to every rank with nbmi_owner_set_all64 before nbmi_owner_step - the
+ * over the ranks (they ride in the exchange of the tree counts), applies the single handle's rule (enter above a third,
+ * leave below a quarter) and hands the verdict to every rank with nbmi_owner_set_all64 before nbmi_owner_step - the
  * arithmetic no longer depends on the world size or on where the splitters fall.  Without a verdict (-1, default) a
  * rank applies the rule to its own waves.
  *
@@ -258,7 +258,7 @@ int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
  *   0  per wave of 64 key-adjacent bodies: float64 where G rho dt^2 of the wave's densest quarter (16 bodies: sum of
  *      G m over the volume of their bounding box, every edge at least one softening length) exceeds `tau`
  *      (default 5e-5; tau = 0 keeps the current value), fp32 elsewhere - and float64 for EVERY wave while most of
- *      the system qualifies (entered when more than half of a step's waves do, left below 40 %).  Default.  The reference computes in float64 throughout
+ *      the system qualifies (entered when more than a third of a step's waves do, left below a quarter).  Default.  The reference computes in float64 throughout
  *      (nbody/simulation.py:246-268); in the dense part of a system fp32's systematic roundings are amplified to
  *      > 1e-4 of the largest coordinate within 100 steps, and where most of the system is that dense the rest
  *      follows.
@@ -288,8 +288,9 @@ int nbmi_frame_set_previous(nbmi_sim *sim, const float *positions_xyz, const flo
 
 /* Test / measurement hook for the device sort behind the octree build ("Morton-code octree build via
  * device radix sort"; it replaces np.argsort of boids/flock.py:618 as well): sorts n (key, value) pairs
- * given as HOST arrays by the low `bits` bits of the key (key_bytes 4 or 8), stable.  impl 0 = the
- * hand-written gfx950 radix sort of csrc/radix.hip (the product path), 1 = rocPRIM (cross-check).
+ * given as HOST arrays by the low `bits` bits of the key (key_bytes 4 or 8), stable.  impl must be 0 = the
+ * hand-written gfx950 radix sort of csrc/radix.hip, the product path (the rocPRIM cross-check is a library of
+ * the tests' own since round 4: tests/native/rocprim_check.hip).
  * *ms_per_sort = mean device time of `repeats` sorts after one untimed run. */
 int nbmi_debug_sort_pairs(int key_bytes, int64_t n, const void *keys, const uint32_t *values, void *keys_out,
                           uint32_t *values_out, int bits, int impl, int repeats, double *ms_per_sort);

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void k_valu(const float4 *__restrict__ posm, i
 }
 
 // 64 i-bodies per wave, 4 waves per block; j-bodies in tiles of 256, re-expressed per wave relative to its centre
+template <int UNROLL, int NACC>
 __global__ __launch_bounds__(256) void k_mfma(const float4 *__restrict__ posm, int n, float eps2, double *__restrict__ out) {
     __shared__ float4 raw[256];
     __shared__ float4 P1[4][256];  // [wave][j]        {-2X, -2Y, -2Z, |X|^2}
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void k_mfma(const float4 *__restrict__ posm, i
             P2[w][lane * 4 + 3] = make_float4(gm[0], gm[1], gm[2], gm[3]);
         }
         __syncthreads();
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+        f4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll UNROLL
         for (int q = 0; q < 64; q++) {
             const float4 a = P1[w][q * 4 + (lane & 3)];
             const float4 g = P2[w][q * 4 + (lane & 3)];
@@ -115,11 +116,19 @@ __global__ __launch_bounds__(256) void k_mfma(const float4 *__restrict__ posm, i
             float f0 = __builtin_amdgcn_rsqf(d[0]), f1 = __builtin_amdgcn_rsqf(d[1]), f2 = __builtin_amdgcn_rsqf(d[2]),
                   f3 = __builtin_amdgcn_rsqf(d[3]);
             f0 = f0 * f0 * f0; f1 = f1 * f1 * f1; f2 = f2 * f2 * f2; f3 = f3 * f3 * f3;
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.x, f0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.y, f1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.z, f2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.w, f3, acc, 0, 0, 0);
+            if (NACC == 2 && (q & 1)) {
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(g.x, f0, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(g.y, f1, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(g.z, f2, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(g.w, f3, acc2, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.x, f0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.y, f1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.z, f2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(g.w, f3, acc, 0, 0, 0);
+            }
         }
+        acc += acc2;
         ax += (double)acc[0] - (double)bx * (double)acc[3];
         ay += (double)acc[1] - (double)by * (double)acc[3];
         az += (double)acc[2] - (double)bz * (double)acc[3];
@@ -221,7 +230,7 @@ int main(int argc, char **argv) {
             std::vector<double> a1(3 * (size_t)n), a2(3 * (size_t)n);
             k_valu<1><<<(n + 255) / 256, 256>>>(d, n, eps * eps, o);
             HC(hipMemcpy(a1.data(), o, (size_t)n * 24, hipMemcpyDeviceToHost));
-            k_mfma<<<(n + 255) / 256, 256>>>(d, n, eps * eps, o);
+            k_mfma<4, 1><<<(n + 255) / 256, 256>>>(d, n, eps * eps, o);
             HC(hipMemcpy(a2.data(), o, (size_t)n * 24, hipMemcpyDeviceToHost));
             const int ns = 1024;
             double e1 = 0, e2 = 0, r1 = 0, r2 = 0;
@@ -253,18 +262,29 @@ int main(int argc, char **argv) {
         HC(hipMemcpy(d, h.data(), (size_t)n * 16, hipMemcpyHostToDevice));
         hipEvent_t e0, e1;
         HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
-        for (int v = 0; v < 2; v++) {
+        for (int v = 0; v < 8; v++) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; rep++) {
                 HC(hipEventRecord(e0));
-                if (v == 0) k_valu<4><<<(n + 1023) / 1024, 256>>>(d, n, eps * eps, o);
-                else k_mfma<<<(n + 255) / 256, 256>>>(d, n, eps * eps, o);
+                const int gb = (n + 255) / 256;
+                switch (v) {
+                case 0: k_valu<4><<<(n + 1023) / 1024, 256>>>(d, n, eps * eps, o); break;
+                case 1: k_valu<1><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 2: k_mfma<1, 1><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 3: k_mfma<2, 1><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 4: k_mfma<4, 1><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 5: k_mfma<8, 1><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 6: k_mfma<4, 2><<<gb, 256>>>(d, n, eps * eps, o); break;
+                case 7: k_mfma<8, 2><<<gb, 256>>>(d, n, eps * eps, o); break;
+                }
                 HC(hipEventRecord(e1)); HC(hipEventSynchronize(e1));
                 float ms; HC(hipEventElapsedTime(&ms, e0, e1));
                 best = std::min(best, ms);
             }
             const double pairs = (double)n * n;
-            printf("%s n=%d: %.2f ms  %.3e pairs/s  %.1f TFLOP/s at 20 flop per pair  %.1f cycles per 64 pairs per SIMD\n", v ? "MFMA" : "VALU", n, best,
+            const char *nm[] = {"VALU IB=4 (1 wave/SIMD at this n)", "VALU IB=1", "MFMA unroll 1", "MFMA unroll 2", "MFMA unroll 4", "MFMA unroll 8",
+                                "MFMA unroll 4, 2 accumulators", "MFMA unroll 8, 2 accumulators"};
+            printf("%-34s n=%d: %.2f ms  %.3e pairs/s  %.1f TFLOP/s at 20 flop per pair  %.1f cycles per 64 pairs per SIMD\n", nm[v], n, best,
                    pairs / (best * 1e-3), 20.0 * pairs / (best * 1e-3) / 1e12, best * 1e-3 * 2.4e9 * 1024.0 / (pairs / 64.0));
         }
     }

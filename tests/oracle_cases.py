@@ -32,6 +32,12 @@ CASES = {
     # Plummer sphere through the BH path, accurate_cluster constants (tools/presets.py:1868-1884)
     "cluster_1m": dict(dist="cluster", n=1_000_000, seed=44, R=300.0, G=0.05, eps=1.0, theta=0.5, dt=0.02,
                        keep=(20, 50, 100), every=1, stem="oracle_cluster_seed44_1000000"),
+    # second held-out set [r4]: made AFTER the system-wide threshold of "auto" was lowered in response to collision_1m
+    # (3.2 x inside the bound with the round-3 thresholds) - inputs nothing was adjusted on
+    "collision_1m_b": dict(dist="collision", n=1_000_000, seed=45, R=1200.0, G=0.08, eps=4.0, theta=0.5, dt=0.2,
+                           keep=(50, 100), every=1, stem="oracle_collision_seed45_1000000"),
+    "galaxy_1m_dt01": dict(dist="galaxy", n=1_000_000, seed=9, R=800.0, G=0.07, eps=1.5, theta=0.5, dt=0.1,
+                           keep=(50, 100), every=1, stem="oracle_galaxy_seed9_dt01_1000000"),
     # BASELINE config 4 / north_star size: uncapped oracle, every 16th body (100 s of 8 cores per step)
     "collision_10m": dict(dist="collision", n=10_000_000, seed=42, R=2000.0, G=0.08, eps=6.0, theta=0.5, dt=0.25,
                           keep=(10, 20, 50, 100), every=16, stem="oracle_collision_10000000"),

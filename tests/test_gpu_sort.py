@@ -9,12 +9,39 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+_CHECK = {}
+
+
+def _rocprim():
+    """tests/native/librocprim_check.so - rocPRIM as the cross-check, in a library of the tests' own (the product
+    library does not contain it); built by __graft_entry__.build(), or here if it is missing."""
+    if "lib" not in _CHECK:
+        import os
+        import subprocess
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "native")
+        so = os.path.join(here, "librocprim_check.so")
+        if not os.path.exists(so):
+            subprocess.run(["make", "-C", here], check=True)
+        lib = C.CDLL(so)
+        lib.rocprim_check_sort_pairs.restype = C.c_int
+        lib.rocprim_check_sort_pairs.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                 C.c_int, C.c_void_p]
+        _CHECK["lib"] = lib
+    return _CHECK["lib"]
+
+
 def _sort(nat, keys, vals, bits, impl, repeats=1):
-    lib = nat.load()
+    """impl 0: the product's radix sort (through the C ABI's debug hook); impl 1: rocPRIM (test-only library)."""
     ko, vo = np.empty_like(keys), np.empty_like(vals)
     ms = C.c_double(0.0)
-    nat.check(lib.nbmi_debug_sort_pairs(keys.dtype.itemsize, len(keys), nat.ptr(keys), nat.ptr(vals), nat.ptr(ko),
-                                        nat.ptr(vo), bits, impl, repeats, C.addressof(ms)), "nbmi_debug_sort_pairs")
+    if impl == 0:
+        lib = nat.load()
+        nat.check(lib.nbmi_debug_sort_pairs(keys.dtype.itemsize, len(keys), nat.ptr(keys), nat.ptr(vals), nat.ptr(ko),
+                                            nat.ptr(vo), bits, 0, repeats, C.addressof(ms)), "nbmi_debug_sort_pairs")
+    else:
+        rc = _rocprim().rocprim_check_sort_pairs(keys.dtype.itemsize, len(keys), nat.ptr(keys), nat.ptr(vals), nat.ptr(ko),
+                                                 nat.ptr(vo), bits, repeats, C.addressof(ms))
+        assert rc == 0, f"rocprim_check_sort_pairs: {rc}"
     return ko, vo, ms.value
 
 
