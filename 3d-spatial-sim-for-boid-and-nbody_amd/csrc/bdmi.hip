@@ -187,6 +187,9 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
                                                   double *__restrict__ o_sep, double *__restrict__ o_ali,
                                                   double *__restrict__ o_coh, double *__restrict__ o_avg,
                                                   int xcd_contiguous) {
+    __shared__ int32_t runs[18][kBlock];  // [2 row, 2 row + 1][thread]: candidate run of the thread's boid in each of its nine rows
+    constexpr int kHitCap = 32;
+    __shared__ unsigned short hits[kHitCap][kBlock];  // [k][thread]: the boid's neighbours found so far, (row << 12) | offset in the row's run
     const int64_t r = logical_block(blockIdx.x, gridDim.x, xcd_contiguous) * kBlock + threadIdx.x;
     if (r >= n) return;
     const double4 pi4 = b.p[r], vi4 = b.v[r], ci4 = b.c[r];
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
         // words of the occupancy table, and what a row costs is a chain of dependent loads (table word -> run
         // bounds -> candidates), not arithmetic: the three rows of a z plane go through each stage TOGETHER, so
         // that their loads are in flight at the same time.  Same rows, same order, same sums as the loop below.
+        bool big = false;
         for (int dcz = -1; dcz <= 1; dcz++) {
             const int ncz = cz + dcz;
             const bool zok = ncz >= 0 && ncz < g.dim;
@@ -276,10 +280,94 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
                     qe[j] = cell_start[k_hi];
                 }
             }
+            // [r4] the runs are only noted here; ONE loop behind the three planes walks all nine (below)
 #pragma unroll
-            for (int j = 0; j < 3; j++)
-                for (int32_t q = qb[j]; q < qe[j]; q++) candidate(q);
+            for (int j = 0; j < 3; j++) {
+                runs[2 * (3 * (dcz + 1) + j)][threadIdx.x] = qb[j];
+                runs[2 * (3 * (dcz + 1) + j) + 1][threadIdx.x] = qe[j];
+                big = big || qe[j] - qb[j] > 4095;
+            }
         }
+        // [r4] One flattened candidate loop per boid instead of nine, in two phases.  In the state flocks reach (53
+        // candidates per boid instead of 9, two thirds of the cells empty, the rest holding more) the nine per-row
+        // loops cost a wave the SUM of the rows' longest runs among its 64 boids; one loop over a lane's nine runs back
+        // to back costs the longest TOTAL.  And only one candidate in six is a neighbour (a sphere of one cell size in
+        // a cube of three), yet nearly every trip of the loop had SOME lane with one, so the wave ran the expensive
+        // half of the body - a float64 square root, four divisions, two dependent 32-byte loads - on every trip with
+        // a sixth of its lanes (66 % of the sweep's wave cycles were waits, 85 vector instructions per trip:
+        // profiles/r04_boids_steady_pmc_summary.json).  Now phase 1 only tests distances, four candidates per trip
+        // with their position records requested together, and notes the neighbours (16 bits each: row and offset in
+        // the row's run) in a per-lane list in LDS; phase 2 walks that list - every lane busy with a real neighbour,
+        // two at a time with all six records in flight.  Same neighbours in the same order: results unchanged bit
+        // for bit.  Sweep at 2 M boids: 0.275 -> 0.218 ms on the initial state, 0.783 -> 0.602 ms after 1000 steps.
+        // (Measured and dropped: phase 1 on an fp32 copy of the positions relative to the cell centres, eight per trip,
+        // float64 re-test inside the fp32 error band - same sets, 0.67 ms: the sweep waits for its gathers, it is not
+        // short of arithmetic or bytes.)
+        int nh = 0;
+        auto neighbour = [&](const double4 qp, const double4 qv, const double4 qc) {  // flock.py:150-172
+            const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
+            const double dist_sq = dx * dx + dy * dy + dz * dz;
+            if (dist_sq < P.separation_sq) {
+                const double dist = sqrt(dist_sq);
+                const double inv_dist = 1.0 / dist;
+                sx += dx * inv_dist / dist;
+                sy += dy * inv_dist / dist;
+                sz += dz * inv_dist / dist;
+                sep_count++;
+            }
+            alx += qv.x; aly += qv.y; alz += qv.z;
+            cox += qp.x; coy += qp.y; coz += qp.z;
+            clr += qc.x; clg += qc.y; clb += qc.z;
+            nb_count++;
+        };
+        auto flush = [&]() {
+            for (int h = 0; h < nh; h += 2) {
+                const unsigned e0 = hits[h][threadIdx.x], e1 = hits[h + 1 < nh ? h + 1 : h][threadIdx.x];
+                const int32_t q0 = runs[2 * (e0 >> 12)][threadIdx.x] + (int32_t)(e0 & 4095u);
+                const int32_t q1 = runs[2 * (e1 >> 12)][threadIdx.x] + (int32_t)(e1 & 4095u);
+                const double4 p0 = b.p[q0], v0 = b.v[q0], c0 = b.c[q0], p1 = b.p[q1], v1 = b.v[q1], c1 = b.c[q1];
+                neighbour(p0, v0, c0);
+                if (h + 1 < nh) neighbour(p1, v1, c1);
+            }
+            nh = 0;
+        };
+        int row = 0;
+        int32_t q = runs[0][threadIdx.x], e = runs[1][threadIdx.x], q_first = q;
+        auto next = [&](unsigned &code) -> int32_t {
+            while (q >= e) {
+                if (row >= 8) { row = 9; return -1; }
+                row++;
+                q = q_first = runs[2 * row][threadIdx.x];
+                e = runs[2 * row + 1][threadIdx.x];
+            }
+            code = ((unsigned)row << 12) | (unsigned)(q - q_first);
+            return q++;
+        };
+        auto test = [&](int32_t c, unsigned code, const double4 qp) {
+            if (c < 0 || c == r) return;
+            const double dx = pix - qp.x, dy = piy - qp.y, dz = piz - qp.z;
+            const double dist_sq = dx * dx + dy * dy + dz * dz;
+            if (dist_sq < P.perception_sq && dist_sq > 0.0001) hits[nh++][threadIdx.x] = (unsigned short)code;
+        };
+        if (big) {
+            // a run of more than 4095 boids (three cells!): its offsets do not fit the 16-bit notes - such a boid
+            // takes its candidates one by one, as the loop for other grids below does
+            for (int k = 0; k < 9; k++)
+                for (int32_t c = runs[2 * k][threadIdx.x]; c < runs[2 * k + 1][threadIdx.x]; c++) candidate(c);
+        } else
+        for (;;) {
+            if (nh > kHitCap - 4) flush();
+            unsigned k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+            const int32_t c0 = next(k0);
+            if (c0 < 0) break;
+            const int32_t c1 = next(k1), c2 = next(k2), c3 = next(k3);
+            const double4 p0 = b.p[c0], p1 = b.p[c1 < 0 ? c0 : c1], p2 = b.p[c2 < 0 ? c0 : c2], p3 = b.p[c3 < 0 ? c0 : c3];
+            test(c0, k0, p0);
+            test(c1, k1, p1);
+            test(c2, k2, p2);
+            test(c3, k3, p3);
+        }
+        flush();
     } else {
     for (int dcz = -g.range; dcz <= g.range; dcz++) {
         const int ncz = cz + dcz;

@@ -255,6 +255,8 @@ def bench_boids(args, n, dt):
         fl.sync()
         torch.cuda.synchronize()
 
+    if args.presteps:  # (profiling the state flocks reach: the timed region starts after this many steps)
+        fl.update(dt, args.presteps)
     fl.update(dt, args.warmup)
     fence()
     t0 = time.perf_counter()
@@ -298,6 +300,55 @@ def bench_boids(args, n, dt):
                         "alg_bytes_per_launch": compulsory, "model_bytes_with_candidates": alg,
                         "model_gbs_with_candidates": model_gbs,
                         "kernel_ms": sweep_ms, "occupied_cells": info["occupied"]}}
+    def candidates_per_boid():
+        """mean number of candidates a boid tests: boids of the 27 cells around its own (itself included)"""
+        cells = np.bincount(fl.cell_indices(), minlength=info["num_cells"]).astype(np.float64)
+        d = info["grid_dim"]
+        box = cells.reshape(d, d, d)  # cell index = x + y d + z d^2 (flock.py:41-43)
+        for ax in range(3):
+            pad = np.pad(box, [(1, 1) if a == ax else (0, 0) for a in range(3)])
+            sl = [slice(None)] * 3
+            acc = np.zeros_like(box)
+            for o in range(3):
+                sl[ax] = slice(o, o + d)
+                acc += pad[tuple(sl)]
+            box = acc
+        per_cell = box.reshape(-1)  # candidates of a boid of that cell
+        order = np.argsort(per_cell, kind="stable")
+        cum = np.cumsum(cells[order]) / n  # share of the boids with at most that many candidates
+        qs = {f"p{int(100 * f)}": float(per_cell[order][np.searchsorted(cum, f)]) for f in (0.5, 0.9, 0.99)}
+        qs["max"] = float(per_cell[cells > 0].max())
+        return float((cells * per_cell).sum() / n), qs
+
+    out["config"]["candidates_per_boid"] = round(candidates_per_boid()[0], 2)
+    if args.steady_steps and not args.presteps:
+        # [r4] the state flocks REACH (VERDICT r3 item 6): the reference runs there, and the sweep costs twice what it
+        # costs on the uniform initial state - cells empty out (occupied cells halve) and the rest fill up
+        done = args.warmup + 2 * args.steps
+        fl.enable_timers(False)
+        fl.update(dt, max(0, args.steady_steps - done))
+        fence()
+        t0 = time.perf_counter()
+        fl.update(dt, args.steps)
+        fence()
+        el2 = time.perf_counter() - t0
+        fl.enable_timers(True)
+        fl.timers(reset=True)
+        fl.update(dt, args.steps)
+        fence()
+        tm2 = fl.timers(reset=True)
+        k2 = max(1, tm2["steps"])
+        info = fl.grid_info()
+        comp2 = n * (96 + 76) + info["num_cells"] // 32 * 8 + info["occupied"] * 4
+        sw2 = tm2["sweep_ms"] / k2
+        out["steady_state"] = {"after_steps": max(done, args.steady_steps), "ms_per_step": 1e3 * el2 / args.steps,
+                               "value": n * args.steps / el2, "unit": "boid-steps/s",
+                               "phase_ms": {key: tm2[key] / k2 for key in ("sort_ms", "table_ms", "sweep_ms")},
+                               "occupied_cells": info["occupied"], "candidates_per_boid": round(candidates_per_boid()[0], 2),
+                               "candidates_per_boid_quantiles": candidates_per_boid()[1],
+                               "roofline": {"bound": "hbm", "kernel": "k_flock", "achieved": comp2 / (sw2 * 1e-3) / 1e9,
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": comp2 / (sw2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "alg_bytes_per_launch": comp2, "kernel_ms": sw2, "traffic": None}}
     if not args.no_cpu_baseline:
         try:
             L = pyref.lib(path=pyref.build(fast=True, native=True, out_dir="/tmp"))
@@ -571,6 +622,10 @@ def main():
     ap.add_argument("--workload", default="galaxy_1m_bh", choices=sorted(WORKLOADS))
     ap.add_argument("--bodies-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--presteps", type=int, default=0,
+                    help="boids: untimed steps before the warm-up (profiles of the state flocks reach)")
+    ap.add_argument("--steady-steps", type=int, default=1000,
+                    help="boids: the line's steady_state object is measured after this many steps (0: skip)")
     ap.add_argument("--skip-10m", action="store_true",
                     help="default run only: leave out the second object (north_star's N = 10 M on this one GPU)")
     ap.add_argument("--dt", type=float, default=None,

@@ -27,9 +27,18 @@ out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/pmc_'+os.environ.get('TAG
 KEYS=('k_walk<true','k_walk<false','k_emit_tile','k_gather_scan','k_scan_subtiles','k_keys','k_tiefix','k_radix_pass','k_radix_hist','k_maxabs','k_direct','k_flock<true','k_reorder','k_table','k_assign')
 agg=collections.defaultdict(lambda: collections.defaultdict(list))
 dur=collections.defaultdict(list)
+LAST=int(os.environ.get('PMC_LAST','0'))  # > 0: only the last PMC_LAST dispatches of each kernel (a state reached late in the run)
 for f in glob.glob(out+'/pass*/*/*counter_collection.csv'):
     seen=set()
-    for r in csv.DictReader(open(f)):
+    rows=list(csv.DictReader(open(f)))
+    if LAST:
+        ids=collections.defaultdict(set)
+        for r in rows:
+            k=[x for x in KEYS if x in r['Kernel_Name']]
+            if k: ids[k[0]].add(int(r['Dispatch_Id']))
+        keep={k: set(sorted(v)[-LAST:]) for k,v in ids.items()}
+        rows=[r for r in rows if any(x in r['Kernel_Name'] and int(r['Dispatch_Id']) in keep[x] for x in keep)]
+    for r in rows:
         n=r['Kernel_Name']
         k=[x for x in KEYS if x in n]
         if not k: continue
