@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
         // a cube of three), yet nearly every trip of the loop had SOME lane with one, so the wave ran the expensive
         // half of the body - a float64 square root, four divisions, two dependent 32-byte loads - on every trip with
         // a sixth of its lanes (66 % of the sweep's wave cycles were waits, 85 vector instructions per trip:
-        // profiles/r04_boids_steady_pmc_summary.json).  Now phase 1 only tests distances, four candidates per trip
+        // profiles/r04_boids_steady_state_ab.txt).  Now phase 1 only tests distances, four candidates per trip
         // with their position records requested together, and notes the neighbours (16 bits each: row and offset in
         // the row's run) in a per-lane list in LDS; phase 2 walks that list - every lane busy with a real neighbour,
         // two at a time with all six records in flight.  Same neighbours in the same order: results unchanged bit
