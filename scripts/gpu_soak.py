@@ -27,10 +27,28 @@ for chunk in range(10):
     st = sim.tree_stats()
     vel = sim.get_velocities()
     pos = sim.get_positions()
+    # [r4] why the step drifts: the share of float64 waves and the work of a walk (counted walk: wave-level visits per
+    # group of 64 bodies), with the phase times of 10 more steps
+    share, all64 = sim.force_precision_share()
+    sim.accelerations()  # one counted walk on the current state
+    ws = sim.walk_counters()
+    sim.enable_timers(True)
+    sim.timers(reset=True)
+    sim.step_many(0.05, 10)
+    sim.sync()
+    tm = sim.timers(reset=True)
+    sim.enable_timers(False)
+    k = max(1, tm["steps"])
     out.append({"steps": 200 * (chunk + 1), "ms_per_step": 1e3 * dt / 200, "nodes": st["num_nodes"], "depth": st["max_depth"],
+                "float64_wave_share": round(share, 3), "every_wave_float64": bool(all64),
+                "wave_visits_per_group": round(ws["wave_visits"] / (len(p) / 64.0), 1),
+                "lane_efficiency": round(ws["lane_visits"] / (64.0 * ws["wave_visits"]), 3),
+                "phase_ms": {q: round(tm[q] / k, 4) for q in ("keys_ms", "sort_ms", "tree_ms", "walk_ms")},
                 "finite": bool(np.isfinite(pos).all() and np.isfinite(vel).all()),
                 "com_speed": float(np.abs(vel.mean(axis=0)).max()), "r_max": float(np.abs(pos).max())})
     print(json.dumps(out[-1]), flush=True)
+if os.environ.get("SOAK_BOIDS", "1") != "1":
+    sys.exit(0)
 fl = Flock(2_000_000, seed=42)
 for chunk in range(10):
     fl.sync()
