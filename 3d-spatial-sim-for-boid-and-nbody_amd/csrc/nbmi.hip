@@ -638,8 +638,8 @@ __device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
 // (chunks of kCellChunk), so the cell list never travels through global memory.
 // Mass / centre of mass of [r, e): see K5-K7.
 // ---------------------------------------------------------------------------------------
-constexpr int kEmitTile = 2048;
-constexpr int kCellChunk = 4096;
+constexpr int kEmitTile = 2048, kEmitTileSmall = 256;
+constexpr int64_t kEmitSmallBodies = 262144;  // up to here the small tile (>= 1024 workgroups from 262 k bodies on either way)
 
 // moments (G m, G m x, G m y, G m z summed) of the bodies at sorted ranks [r, e): in-tile prefix differences, plus
 // the double-double tile prefixes where the range crosses tiles
@@ -667,6 +667,11 @@ __device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t
     if (node_ref) node_ref[total] = -1;
 }
 
+// [r4] TILE is a template parameter: 2 048 ranks per workgroup where there are workgroups to spare, 256 for small
+// systems - at 10 k bodies five workgroups of 2 048 ranks took 58 us (the tile's serial phases, an empty chip), forty of 256 take
+// a quarter of that.  Only the decomposition changes (a cell that reaches beyond its tile is found by the key search
+// either way): the nodes written are the same.
+template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict__ delta, const int32_t *__restrict__ PexL,
                                                       const int32_t *__restrict__ subPex, const double4 *__restrict__ S,
                                                       const Moment *__restrict__ T, const float4 *__restrict__ posm_s,
@@ -679,11 +684,11 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
                                                       const uint32_t *__restrict__ perm, double G, TreeInfo *info,
                                                       int64_t link_base /* owner mode: the arrays passed in begin at this row of
                                                                            the walk array, and the links count from ITS start */) {
-    __shared__ uint8_t tree[2 * kEmitTile];   // heap: tree[kEmitTile + i] = delta[base + i] + 1, inner nodes = min of children
+    __shared__ uint8_t tree[2 * TILE];   // heap: tree[TILE + i] = delta[base + i] + 1, inner nodes = min of children
     __shared__ uint8_t dprev;                 // delta[base - 1] + 1
-    __shared__ uint32_t cells[kCellChunk];    // node slot -> (local body index << 6) | k (k-th node of that body)
+    __shared__ uint32_t cells[(2 * TILE)];    // node slot -> (local body index << 6) | k (k-th node of that body)
     const int t = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kEmitTile;
+    const int64_t base = (int64_t)blockIdx.x * TILE;
     const int64_t total = n + pex_at(PexL, subPex, n);
     if (blockIdx.x == 0 && t == 0) {
         info->num_nodes = total;
@@ -702,13 +707,13 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
     }
     if (total + 1 > capacity) return;
     // delta of the tile as bytes (ranks >= n - 1 count as -1: nothing reaches across the end of the array)
-    for (int i = t; i < kEmitTile; i += kBlock) {
+    for (int i = t; i < TILE; i += kBlock) {
         const int64_t r = base + i;
-        tree[kEmitTile + i] = (uint8_t)((r < n ? delta[r] : -1) + 1);
+        tree[TILE + i] = (uint8_t)((r < n ? delta[r] : -1) + 1);
     }
     if (t == 0) dprev = (uint8_t)((base > 0 ? delta[base - 1] : -1) + 1);
     __syncthreads();
-    for (int width = kEmitTile / 2; width >= 1; width >>= 1) {
+    for (int width = TILE / 2; width >= 1; width >>= 1) {
         for (int i = t; i < width; i += kBlock) {
             const uint8_t a = tree[2 * (width + i)], b = tree[2 * (width + i) + 1];
             tree[width + i] = a < b ? a : b;
@@ -716,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
         __syncthreads();
     }
     const int64_t q_tile = pex_at(PexL, subPex, base < n ? base : n);
-    const int64_t tile_end = base + kEmitTile < n ? base + kEmitTile : n;
+    const int64_t tile_end = base + TILE < n ? base + TILE : n;
     const int64_t ncell = pex_at(PexL, subPex, tile_end) - q_tile;  // cells started inside this tile
     const int64_t nnode = (tile_end - base) + ncell;                // the tile's nodes: one contiguous run of indices
     const int64_t idx0 = base + q_tile;                             // ... starting here
@@ -725,30 +730,30 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
     // The tile's nodes are written in INDEX order, consecutive lanes = consecutive nodes (a wave's stores of the
     // 24 / 40 / 32-byte records then cover one contiguous stretch of each array; a thread per body / per cell wrote
     // every record into a different cache line: 2.3 TB/s of mostly partial-line traffic at 10 M bodies).  Which
-    // (body, k) a node index belongs to comes from a table in LDS that the bodies fill, kCellChunk slots at a time:
+    // (body, k) a node index belongs to comes from a table in LDS that the bodies fill, (2 * TILE) slots at a time:
     // local node slot of body i's k-th node (its cnt cells, then its leaf) = i + (pex(r) - q_tile) + k.
-    for (int64_t c0 = 0; c0 < nnode; c0 += kCellChunk) {
-        for (int i = t; i < kEmitTile; i += kBlock) {
+    for (int64_t c0 = 0; c0 < nnode; c0 += (2 * TILE)) {
+        for (int i = t; i < TILE; i += kBlock) {
             const int64_t r = base + i;
             if (r >= n) break;
-            const int d = (int)tree[kEmitTile + i] - 1;
-            const int dp = (int)(i > 0 ? tree[kEmitTile + i - 1] : dprev) - 1;
+            const int d = (int)tree[TILE + i] - 1;
+            const int dp = (int)(i > 0 ? tree[TILE + i - 1] : dprev) - 1;
             const int cnt = d > dp ? d - dp : 0;
             const int64_t s0 = i + (pex_at(PexL, subPex, r) - q_tile) - c0;
             for (int k = 0; k <= cnt; k++) {
                 const int64_t c = s0 + k;
-                if (c >= 0 && c < kCellChunk) cells[c] = ((uint32_t)i << 6) | (uint32_t)k;
+                if (c >= 0 && c < (2 * TILE)) cells[c] = ((uint32_t)i << 6) | (uint32_t)k;
             }
         }
         __syncthreads();
-        const int64_t here = nnode - c0 < kCellChunk ? nnode - c0 : kCellChunk;
+        const int64_t here = nnode - c0 < (2 * TILE) ? nnode - c0 : (2 * TILE);
         for (int64_t c = t; c < here; c += kBlock) {
             const uint32_t cl = cells[c];
             const int i = (int)(cl >> 6), k = (int)(cl & 63u);
             const int64_t r = base + i;
             const int64_t idx = idx0 + c0 + c;
-            const int d = (int)tree[kEmitTile + i] - 1;
-            const int dp = (int)(i > 0 ? tree[kEmitTile + i - 1] : dprev) - 1;
+            const int d = (int)tree[TILE + i] - 1;
+            const int dp = (int)(i > 0 ? tree[TILE + i - 1] : dprev) - 1;
             const int cnt = d > dp ? d - dp : 0;
             if (k == cnt) {  // the body's leaf
                 const float4 p = posm_s[r];
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             }
             const int lev = dp + 1 + k;
             // first local index j >= i with delta[j] + 1 <= lev
-            unsigned h = (unsigned)(kEmitTile + i);
+            unsigned h = (unsigned)(TILE + i);
             bool found = false;
             for (;;) {
                 if ((int)tree[h] <= lev) { found = true; break; }
@@ -780,15 +785,15 @@ __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict_
             }
             int64_t e;
             if (found) {
-                while (h < (unsigned)kEmitTile) {
+                while (h < (unsigned)TILE) {
                     h <<= 1;
                     if ((int)tree[h] > lev) h += 1u;
                 }
-                e = base + (int64_t)(h - (unsigned)kEmitTile) + 1;
+                e = base + (int64_t)(h - (unsigned)TILE) + 1;
             } else {
                 // the cell reaches beyond the tile: gallop + binary search on the sorted keys from the tile's end on
                 const uint64_t kh = hi_s[r], kl = lo_s[r];
-                int64_t ok = base + kEmitTile - 1, bad, step = 1;
+                int64_t ok = base + TILE - 1, bad, step = 1;
                 for (;;) {
                     const int64_t u = ok + step;
                     if (u >= n) { bad = n; break; }
@@ -1754,6 +1759,10 @@ __global__ __launch_bounds__(64 * K) void k_walk_split(const Node *__restrict__ 
     // wave-uniform range (w is the wave index): tell the compiler so
     // (owner mode: rows [1, walk_first) behind the jump node at row 0 are unused; the parts divide the rest)
     const int64_t first = frozen ? 0 : info_in->walk_first, span = num_nodes - first;
+    // ([r4] measured and dropped: parts graded by distance from the group's own leaves - the K waves sharing the two sides
+    // of the home leaf in proportion to their octaves of distance, a side's parts ending at home +- 48 * 2^(t octaves / parts)
+    // nodes.  Walk 0.076 -> 0.096 ms at 10 k bodies, 0.157 -> 0.182 at 30 k, 0.216 -> 0.244 at 100 k, 0.475 -> 0.454 at
+    // 262 k: a galaxy's visits are spread over the far field more evenly than one per octave, equal K-ths stay.)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(w == 0 ? 0 : first + span * w / K) * kNodeBytes);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(first + span * (w + 1) / K) * kNodeBytes);
     // [r3] force precision of the group (all K waves of the workgroup walk the same 64 bodies): as in k_walk
@@ -3319,7 +3328,13 @@ int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     const int64_t ob = s->own_base;  // (owner mode: the own tree begins at this row of the walk array; node_level / node_ref / diag64 count from the tree's start)
-    k_emit_tile<<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
+    if (n <= kEmitSmallBodies)
+        k_emit_tile<kEmitTileSmall><<<(int)((n + kEmitTileSmall - 1) / kEmitTileSmall), kBlock, 0, st>>>(
+        s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
+        inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
+        s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob);
+    else
+        k_emit_tile<kEmitTile><<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
         s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
         inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
         s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob);
