@@ -1,6 +1,6 @@
 """Owner mode (locally essential trees) over 100 steps: BASELINE config 2's 1 M-body galaxy on EIGHT virtual ranks
 (threads on one GPU, LetBarnesHut.step itself) against the float64 oracle trajectory of tests/cache
-(scripts/oracle_traj_cache.py), per force-precision mode.  Error = max |x - x_ref|_inf / max |x_ref|.
+(scripts/oracle_cache.py galaxy_1m), per force-precision mode.  Error = max |x - x_ref|_inf / max |x_ref|.
 
     python scripts/gpu_owner_100.py [world] [modes]        -> one JSON line per (mode, checkpoint)
 """

@@ -1,6 +1,6 @@
 """Config 4 in its north-star form: the 10 M-body collision (theta 0.5, dt 0.25) owned by EIGHT ranks of 1.25 M bodies
 (threads on one GPU through LetBarnesHut.step itself) against the uncapped oracle's trajectory of
-scripts/oracle_traj_cache_10m.py (every 16th body at steps 10 / 20 / 50 / 100 under tests/cache/).
+scripts/oracle_cache.py collision_10m (every 16th body at steps 10 / 20 / 50 / 100 under tests/cache/).
 Error = max |x - x_ref|_inf / max |x_ref|.      python scripts/gpu_owner_10m.py [world] [mode]
 """
 import glob

@@ -1,5 +1,5 @@
 """Force-precision modes at the north-star size: collision, 10 M bodies, theta 0.5, dt 0.25, against the oracle
-trajectory of scripts/oracle_traj_cache_10m.py (every 16th body, steps 10 / 20 / 50 / 100 as far as they exist).
+trajectory of scripts/oracle_cache.py collision_10m (every 16th body, steps 10 / 20 / 50 / 100 as far as they exist).
 MODES = f32 | f64 | auto:<tau>."""
 import glob
 import importlib

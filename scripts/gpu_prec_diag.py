@@ -1,6 +1,6 @@
 """Which rounding makes the 100-step position error at BASELINE config 2 (galaxy, 1 M bodies, theta 0.5, dt 0.05)?
 Runs the GPU for 100 steps once per arithmetic mode of k_walk_diag (NBMI_PREC, see csrc/nbmi.hip; 0 = the product
-walk) and compares with the oracle trajectory cached by scripts/oracle_traj_cache.py (tests/cache/, made in the build
+walk) and compares with the oracle trajectory cached by scripts/oracle_cache.py galaxy_1m (tests/cache/, made in the build
 container: the oracle costs ~4 minutes of the GPU box's CPU otherwise).  One JSON line per (mode, snapshot)."""
 import glob
 import importlib
