@@ -624,7 +624,7 @@ __device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
 }
 
 // ---------------------------------------------------------------------------------------
-// K8 [r3]: emit the nodes in DFS pre-order, one workgroup per tile of kEmitTile sorted ranks.
+// K8 [r3]: emit the nodes in DFS pre-order, one workgroup per tile of TILE sorted ranks (kEmitTile / kEmitTileSmall).
 // Pre-order index of a node "started" by sorted body r (dp = delta[r-1], d = delta[r], cnt = max(0, d - dp)):
 //   internal cell k of r (level dp+1+k, k < cnt) -> r + pex(r) + k,     leaf of r -> r + pex(r) + cnt.
 // A cell (r, lev) holds the bodies [r, e), e - 1 = the first j >= r with delta[j] < lev ("nearest smaller value to
@@ -638,7 +638,7 @@ __device__ __forceinline__ unsigned band_half_ulps(double maxabs, double eps) {
 // (chunks of kCellChunk), so the cell list never travels through global memory.
 // Mass / centre of mass of [r, e): see K5-K7.
 // ---------------------------------------------------------------------------------------
-constexpr int kEmitTile = 2048, kEmitTileSmall = 256;
+constexpr int kEmitTile = 512, kEmitTileSmall = 256;
 constexpr int64_t kEmitSmallBodies = 262144;  // up to here the small tile (>= 1024 workgroups from 262 k bodies on either way)
 
 // moments (G m, G m x, G m y, G m z summed) of the bodies at sorted ranks [r, e): in-tile prefix differences, plus
@@ -667,10 +667,11 @@ __device__ __forceinline__ void write_sentinel(Node *__restrict__ nodes, int32_t
     if (node_ref) node_ref[total] = -1;
 }
 
-// [r4] TILE is a template parameter: 2 048 ranks per workgroup where there are workgroups to spare, 256 for small
-// systems - at 10 k bodies five workgroups of 2 048 ranks took 58 us (the tile's serial phases, an empty chip), forty of 256 take
-// a quarter of that.  Only the decomposition changes (a cell that reaches beyond its tile is found by the key search
-// either way): the nodes written are the same.
+// [r4] TILE is a template parameter.  Round 3 used 2 048 ranks per workgroup throughout; measured this round
+// (profiles/r04_emit_tile_sweep.txt): tree phase at 1 M bodies 0.147 ms with 2 048, 0.134 / 0.133 / 0.135 with 1 024 / 512 /
+// 256; at 10 M 1.32 / 1.18 / 1.16 / 1.26 ms; at 10 k bodies five workgroups of 2 048 ranks took 58 us (the tile's serial
+// phases, an empty chip), forty of 256 a quarter of that.  512 ships, 256 up to 262 k bodies.  Only the decomposition
+// changes (a cell that reaches beyond its tile is found by the key search either way): the nodes written are the same.
 template <int TILE>
 __global__ __launch_bounds__(kBlock) void k_emit_tile(const int32_t *__restrict__ delta, const int32_t *__restrict__ PexL,
                                                       const int32_t *__restrict__ subPex, const double4 *__restrict__ S,
@@ -3328,16 +3329,16 @@ int enqueue_global_tree(nbmi_sim *s, bool aux = true) {
     // theta = 0 means "never accept an internal node": s2t = +inf
     const double inv_theta2 = s->theta > 0.0 ? 1.0 / (s->theta * s->theta) : INFINITY;
     const int64_t ob = s->own_base;  // (owner mode: the own tree begins at this row of the walk array; node_level / node_ref / diag64 count from the tree's start)
-    if (n <= kEmitSmallBodies)
-        k_emit_tile<kEmitTileSmall><<<(int)((n + kEmitTileSmall - 1) / kEmitTileSmall), kBlock, 0, st>>>(
-        s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
-        inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
-        s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob);
-    else
-        k_emit_tile<kEmitTile><<<(int)((n + kEmitTile - 1) / kEmitTile), kBlock, 0, st>>>(
-        s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,
-        inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,
-        s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob);
+    {
+        const int tile = n <= kEmitSmallBodies ? kEmitTileSmall : kEmitTile;
+#define NBMI_EMIT(TV) k_emit_tile<TV><<<(int)((n + TV - 1) / TV), kBlock, 0, st>>>(                                         \
+        s->delta, s->Pex, s->subPex, s->S, s->T, s->t_posm, s->p64_s, s->t_hi, s->t_lo, n, s->own_node_rows, s->softening,       \
+        inv_theta2, s->nodes + ob, s->nodes64 + ob, aux ? s->node_level : nullptr, aux ? s->node_ref : nullptr, s->diag64,   \
+        s->force_prec != 1 && s->nodesd ? s->nodesd + ob : nullptr, s->buf[s->curbuf], s->perm, s->G, s->info, ob)
+        if (tile == kEmitTileSmall) NBMI_EMIT(kEmitTileSmall);
+        else NBMI_EMIT(kEmitTile);
+#undef NBMI_EMIT
+    }
     if (s->walk_stack)
         k_child_table<<<nblocks(s->own_node_rows), kBlock, 0, st>>>(s->nodes, s->info, s->own_node_rows, s->child_tab);
     NBMI_HIP_CHECK(hipGetLastError());
