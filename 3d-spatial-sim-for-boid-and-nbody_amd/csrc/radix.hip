@@ -28,9 +28,9 @@ constexpr int kRadixBits = 8;
 constexpr int kBins = 1 << kRadixBits;
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kItems = 16;                  // pairs per thread
-constexpr int kTile = kThreads * kItems;    // 4 096 pairs per workgroup
-constexpr int kWaveChunk = 64 * kItems;     // a wave ranks 1 024 consecutive pairs
+constexpr int kItems = 16, kItemsMin = 4;   // pairs per thread: a workgroup's tile is 4 096 (or 2 048) pairs, a wave ranks 1 024 (512)
+                                            // consecutive ones (template parameter of k_radix_pass; the status words are
+                                            // sized for the smaller tile)
 constexpr unsigned kFlagAgg = 1u << 30, kFlagIncl = 2u << 30, kValueMask = (1u << 30) - 1;
 constexpr int kLookBatch = 8;
 constexpr int kMaxPasses = 8;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBins) void k_radix_offsets(Control *ctl) {
 }
 
 // ---- one pass --------------------------------------------------------------------------------
-template <typename K>
+template <typename K, int ITEMS>
 __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ kin, K *__restrict__ kout,
                                                         const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                         int64_t n, int shift, int pass, Control *ctl,
@@ -111,24 +111,24 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     __shared__ unsigned wave_tot[kWaves];
     // the reorder buffer is used twice, for the keys and then for the values (38 KB instead of 54 KB of LDS:
     // four workgroups per CU instead of two)
-    __shared__ K lds_k[kTile];
+    __shared__ K lds_k[(kThreads * ITEMS)];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) s_tile = atomicAdd(&ctl->tile_ticket[pass], 1u);
     for (int i = t; i < kWaves * kBins; i += kThreads) (&cnt_w[0][0])[i] = 0u;
     __syncthreads();
     const unsigned tile = s_tile;
-    const int64_t tile_base = (int64_t)tile * kTile;
-    const int valid_in_tile = (int)((n - tile_base) < kTile ? (n - tile_base) : kTile);
+    const int64_t tile_base = (int64_t)tile * (kThreads * ITEMS);
+    const int valid_in_tile = (int)((n - tile_base) < (kThreads * ITEMS) ? (n - tile_base) : (kThreads * ITEMS));
 
-    // a wave owns kWaveChunk consecutive pairs and loads them 64 at a time (coalesced); the order inside
+    // a wave owns (64 * ITEMS) consecutive pairs and loads them 64 at a time (coalesced); the order inside
     // the tile is wave-major, then round, then lane
-    K key[kItems];
-    uint32_t val[kItems];
-    unsigned rank[kItems];
-    const int64_t wave_base = tile_base + (int64_t)w * kWaveChunk;
+    K key[ITEMS];
+    uint32_t val[ITEMS];
+    unsigned rank[ITEMS];
+    const int64_t wave_base = tile_base + (int64_t)w * (64 * ITEMS);
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int64_t idx = wave_base + i * 64 + lane;
         const bool ok = idx < n;
         key[i] = ok ? kin[idx] : (K)~(K)0;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int64_t idx = wave_base + i * 64 + lane;
         const bool ok = idx < n;
         const unsigned d = digit_of(key[i], shift);
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     __syncthreads();
 
     // reorder inside the tile: digit runs, each in input order
-    unsigned slot[kItems / 2];  // two 16-bit slots per register
+    unsigned slot[ITEMS / 2];  // two 16-bit slots per register
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int64_t idx = wave_base + i * 64 + lane;
         unsigned q = 0;
         if (idx < n) {
@@ -230,9 +230,9 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
         if (i & 1) slot[i >> 1] |= q << 16; else slot[i >> 1] = q;
     }
     __syncthreads();
-    unsigned dst[kItems];
+    unsigned dst[ITEMS];
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int q = i * kThreads + t;
         if (q < valid_in_tile) {
             const K k = lds_k[q];
@@ -243,20 +243,20 @@ __global__ __launch_bounds__(kThreads) void k_radix_pass(const K *__restrict__ k
     __syncthreads();
     uint32_t *lds_v = reinterpret_cast<uint32_t *>(lds_k);
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int64_t idx = wave_base + i * 64 + lane;
         if (idx < n) lds_v[(slot[i >> 1] >> ((i & 1) * 16)) & 0xffffu] = val[i];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < kItems; i++) {
+    for (int i = 0; i < ITEMS; i++) {
         const int q = i * kThreads + t;
         if (q < valid_in_tile) vout[dst[i]] = lds_v[q];
     }
 }
 
 inline int passes_for(int bits) { return (bits + kRadixBits - 1) / kRadixBits; }
-inline size_t tiles_for(size_t n) { return (n + kTile - 1) / kTile; }
+inline size_t tiles_for(size_t n, int items = kItemsMin) { return (n + (size_t)kThreads * items - 1) / ((size_t)kThreads * items); }
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 template <typename K>
@@ -276,9 +276,13 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
     if (passes < 1 || passes > kMaxPasses || temp_size < temp_bytes<K>(n, bits)) return hipErrorInvalidValue;
     char *base = (char *)temp;
     Control *ctl = (Control *)base;
-    const size_t tiles = tiles_for(n);
+    // [r4] pairs per thread by size (profiles/r04_small_systems.txt): a pass over few pairs is a chain of latencies, and
+    // more, smaller workgroups shorten it - sort phase at 10 k bodies 0.067 / 0.054 / 0.050 ms with 16 / 8 / 4, at 262 k
+    // 0.126 / 0.120 / 0.125; from 1 M on the large tile wins (0.151 against 0.169 ms with 8, 10 M: 0.70 against 0.82)
+    const int items = n <= 65536 ? 4 : (n <= 524288 ? 8 : kItems);
+    const size_t tiles = tiles_for(n, items);
     unsigned *status = (unsigned *)(base + align256(sizeof(Control)));
-    const size_t status_bytes = align256((size_t)passes * tiles * kBins * sizeof(unsigned));
+    const size_t status_bytes = align256((size_t)passes * tiles_for(n) * kBins * sizeof(unsigned));
     K *ktmp = (K *)((char *)status + status_bytes);
     uint32_t *vtmp = (uint32_t *)((char *)ktmp + align256(n * sizeof(K)));
     // everything but the sticky error word at the head of the control block
@@ -296,8 +300,15 @@ hipError_t sort_pairs(void *temp, size_t temp_size, const K *kin, K *kout, const
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         K *kdst = to_out ? kout : ktmp;
         uint32_t *vdst = to_out ? vout : vtmp;
-        k_radix_pass<K><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, begin_bit + p * kRadixBits, p, ctl,
-                                                         status + (size_t)p * tiles * kBins);
+        if (items == 4)
+            k_radix_pass<K, 4><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, begin_bit + p * kRadixBits, p, ctl,
+                                                                status + (size_t)p * tiles * kBins);
+        else if (items == 8)
+            k_radix_pass<K, 8><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, begin_bit + p * kRadixBits, p, ctl,
+                                                                status + (size_t)p * tiles * kBins);
+        else
+            k_radix_pass<K, 16><<<(int)tiles, kThreads, 0, st>>>(ksrc, kdst, vsrc, vdst, (int64_t)n, begin_bit + p * kRadixBits, p, ctl,
+                                                                 status + (size_t)p * tiles * kBins);
         ksrc = kdst;
         vsrc = vdst;
     }
