@@ -80,7 +80,7 @@ WORKLOADS = {
 }
 
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def csrc_sha():
