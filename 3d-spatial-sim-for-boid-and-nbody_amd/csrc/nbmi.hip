@@ -3880,6 +3880,8 @@ int nbmi_set_state(nbmi_sim *s, const double *pos, const double *vel) {
     NBMI_HIP_CHECK(hipGetLastError());
     NBMI_HIP_CHECK(hipMemsetAsync(&s->info->sticky_error, 0, sizeof(int), s->stream));  // a fresh state: drop a pending capacity error
     NBMI_HIP_CHECK(hipStreamSynchronize(s->stream));
+    k_set_all64<<<1, 1, 0, s->stream>>>(s->info, 0);  // a new state: the "most of the system asks" history is the old system's
+    NBMI_HIP_CHECK(hipGetLastError());
     s->tree_valid = false;
     s->maxabs_fused = false;
     return 0;

@@ -113,6 +113,13 @@ def pmc_traffic(workload, kernel_key):
         return None
 
 
+def issue_floor(cycles_per_visit, asked_share, every_wave, forced):
+    s = 1.0 if (every_wave or forced == "f64") else (0.0 if forced == "f32" else float(asked_share))
+    floor = 38.0 + s * (82.0 - 38.0)
+    return {"cycles_per_wave_visit_per_simd": cycles_per_visit, "float64_visit_cycles": 82, "fp32_visit_cycles": 38,
+            "float64_share_of_waves": round(s, 4), "floor_cycles": floor, "frac": floor / cycles_per_visit}
+
+
 def make_ic(dist_name, n, R, G):
     from tools.presets import generate_distribution
     np.random.seed(42)
@@ -585,11 +592,12 @@ def measure_nbody(args, workload, world, rank, dev, use_dist, steps, warmup, cpu
                                "lane_visits_per_body": wc["lane_visits"] / n_total,
                                "interactions_per_s": wc["lane_accepts"] / (walk_ms * 1e-3),
                                "tie_visits_redecided_f64": wc["band_visits"],
-                               # second reading: this kernel is bound by vector-instruction issue and
-                               # its per-wave load chain, not by HBM: 17 VALU instructions per wave-level visit at the
-                               # measured 2.8 cycles per instruction per SIMD (scripts/ubench), 1024 SIMDs, 2.4 GHz
-                               "valu_issue": {"valu_per_visit": 17, "cycles_per_valu": 2.8,
-                                              "cycles_per_visit_per_simd": cyc, "frac": 17 * 2.8 / cyc},
+                               # second reading: this kernel is not HBM-bound.  What it can be held to is
+                               # the vector-issue time of its visits: a float64 visit is 17 float64-rate + 3 fp32-rate
+                               # instructions + v_rsq_f32 = 82 cycles of its SIMD at the architectural rates (4 / 2 / 8),
+                               # an fp32 visit 38; 1024 SIMDs at 2.4 GHz.  The float64 share of the VISITS is taken as the
+                               # share of the waves (dense waves visit more: the floor is a little higher than this).
+                               "issue_floor": issue_floor(cyc, *sim.force_precision_share(), args.force_precision),
                                "lane_efficiency": wc["lane_visits"] / max(1, 64 * wc["wave_visits"]),
                                "num_nodes": ts["num_nodes"], "max_depth": ts["max_depth"],
                                "jumps_per_group": wc["jumps"] / groups,

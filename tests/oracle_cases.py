@@ -38,6 +38,10 @@ CASES = {
                            keep=(50, 100), every=1, stem="oracle_collision_seed45_1000000"),
     "galaxy_1m_dt01": dict(dist="galaxy", n=1_000_000, seed=9, R=800.0, G=0.07, eps=1.5, theta=0.5, dt=0.1,
                            keep=(50, 100), every=1, stem="oracle_galaxy_seed9_dt01_1000000"),
+    # the reference's LIVE configuration (config/nbody.py:16-17, 57-73: 150 000 bodies, theta 0.8, G 0.1, eps 2.0,
+    # R 500; NBodySimulation.update caps dt at 0.02, simulation.py:802)
+    "live_150k": dict(dist="galaxy", n=150_000, seed=3, R=500.0, G=0.1, eps=2.0, theta=0.8, dt=0.02,
+                      keep=(100,), every=1, stem="oracle_live_galaxy_seed3_150000"),
     # BASELINE config 4 / north_star size: uncapped oracle, every 16th body (100 s of 8 cores per step)
     "collision_10m": dict(dist="collision", n=10_000_000, seed=42, R=2000.0, G=0.08, eps=6.0, theta=0.5, dt=0.25,
                           keep=(10, 20, 50, 100), every=16, stem="oracle_collision_10000000"),

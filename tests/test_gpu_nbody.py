@@ -820,3 +820,63 @@ def test_random_trees_vs_oracle_stress(gpu, oracle):
         assert err <= bound, (case, n, kind, err, bound)
         sim.close()
     print("stress: worst error / stated bound =", worst)
+
+
+def test_system_wide_float64_rule_has_hysteresis(gpu):
+    """[r4] Force precision "auto": every wave computes in float64 from the step in which more than a third of the
+    waves ask for it until fewer than a quarter do.  tau moves the share of asking waves on one and the same system:
+    above a third -> on; back between a quarter and a third -> stays on (a fresh handle there says off); below a quarter
+    -> off; between the two again -> stays off.  nbmi_set_state drops the history."""
+    from nbody.gpu_backend import HIPBarnesHutSimulation
+    from tools.presets import generate_distribution
+    np.random.seed(5)
+    n = 200_000
+    p, v, m = generate_distribution("galaxy", n, 800.0, 0.07)
+    sim = HIPBarnesHutSimulation(p, v, m, 0.07, 1.5, 1.0, 0.5)
+    dt = 0.02
+
+    def step_at(tau):
+        sim.set_force_precision("auto", tau)
+        sim.step(dt)
+        return sim.force_precision_share()
+
+    def tau_for(lo_share, hi_share):
+        """a tau whose share of asking waves lies inside (lo_share, hi_share) on the current state: bisection on log tau
+        with a probe handle (the handle under test keeps its history).  The probe takes vanishing steps, so that the
+        state does not move under the search; the criterion is G rho dt^2 > tau, hence the factor between the taus."""
+        shrink = 1e-6
+        probe = HIPBarnesHutSimulation(sim.get_positions_f64(), sim.get_velocities(), m, 0.07, 1.5, 1.0, 0.5)
+        a, b = 1e-12, 1e2  # share(a) ~ 1, share(b) ~ 0
+        try:
+            for _ in range(80):
+                t = float(np.sqrt(a * b))
+                probe.set_force_precision("auto", t * shrink ** 2)
+                probe.step(dt * shrink)
+                sh = probe.force_precision_share()[0]
+                if lo_share < sh < hi_share:
+                    return t
+                if sh >= hi_share:
+                    a = t
+                else:
+                    b = t
+        finally:
+            probe.close()
+        pytest.skip("no tau gives a share inside the asked window on this input")
+
+    t_hi, t_mid, t_lo = tau_for(0.40, 0.60), tau_for(0.27, 0.32), tau_for(0.05, 0.20)
+    sh, on = step_at(t_mid)
+    assert 0.25 < sh < 1 / 3 and not on, (sh, on)        # a fresh system between the thresholds: off
+    sh, on = step_at(t_hi)
+    assert sh > 1 / 3 and on, (sh, on)                   # above a third: on
+    sh, on = step_at(t_mid)
+    assert 0.25 <= sh < 1 / 3 and on, (sh, on)           # back between the two: stays on
+    sh, on = step_at(t_lo)
+    assert sh < 0.25 and not on, (sh, on)                # below a quarter: off
+    sh, on = step_at(t_mid)
+    assert 0.25 < sh < 1 / 3 and not on, (sh, on)        # between the two again: stays off
+    step_at(t_hi)
+    assert sim.force_precision_share()[1]
+    sim.set_state(sim.get_positions_f64(), sim.get_velocities())
+    sh, on = step_at(t_mid)
+    assert not on, "nbmi_set_state must drop the history"
+    sim.close()

@@ -25,8 +25,8 @@ def _errors(x, ref):
     return float(d.max()), float(np.quantile(d, 0.999)), float(np.sqrt((d ** 2).mean()))
 
 
-@pytest.mark.parametrize("case", ["galaxy_1m_seed7", "collision_1m", "cluster_1m", "collision_1m_b", "galaxy_1m_dt01"])
-def test_held_out_1m_inputs_100_steps_default_precision(gpu, oracle, case):
+@pytest.mark.parametrize("case", ["galaxy_1m_seed7", "collision_1m", "cluster_1m", "collision_1m_b", "galaxy_1m_dt01", "live_150k"])
+def test_held_out_inputs_100_steps_default_precision(gpu, oracle, case):
     from nbody.gpu_backend import HIPBarnesHutSimulation
     c = oracle_cases.CASES[case]
     p, v, m, ref = oracle_cases.load(case, (100,), oracle)
