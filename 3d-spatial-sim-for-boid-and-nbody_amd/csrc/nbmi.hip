@@ -2855,8 +2855,24 @@ __global__ __launch_bounds__(kBlock) void k_let_mark(const Node *__restrict__ no
     const double thr = all ? 0.0 : (size / theta) * (size / theta) * (1.0 + 1e-9);
     const int64_t nx = nd.next_off >= kLinkTag ? N : (int64_t)(nd.next_off / kNodeBytes) - link_base;  // (a subtree that leaves the rank: to the end of the array)
     if (nx <= i + 1) return;
+    // [r4] A cell whose PARENT no body of rank j can open lies inside the range the parent drops for j: it has nothing to
+    // add (13 of 14 marks of a deep cell were of that kind: two atomics each).  The parent is the cube of edge 2 size around
+    // this cell; its centre of mass and ours both lie in it, at most its diagonal 2 sqrt(3) size apart, so every point b of
+    // rank j's box is at least d(b, our centre of mass) - 2 sqrt(3) size from the parent's: the parent passes the opening
+    // test for all of rank j when d^2 > reach^2.  (Skipping a mark can only keep a node that could have been dropped -
+    // the exported piece stays correct whatever this test does; the parent's own test is the exact one.)
+    const double far = sqrt(fmax(0.0, 4.0 * thr * (1.0 + 1e-6) - eps2)) + 3.4642 * size;
+    const double reach2 = i > 0 ? far * far : INFINITY;
     for (int j = 0; j < world; j++) {
         if (j == me) continue;
+        if (!all) {
+            const double *rb = rankbox + 6 * j;
+            if (rb[0] <= rb[3]) {
+                const double dx = fmax(0.0, fmax(rb[0] - c.cx, c.cx - rb[3])), dy = fmax(0.0, fmax(rb[1] - c.cy, c.cy - rb[4])),
+                             dz = fmax(0.0, fmax(rb[2] - c.cz, c.cz - rb[5]));
+                if (dx * dx + dy * dy + dz * dz > reach2) continue;
+            }
+        }
         if (!all && !rank_may_open(j, c, eps2, thr, boxes, supers, megas, rankbox)) {
             int32_t *d = diff + (int64_t)j * stride;
             atomicAdd(&d[i + 1], 1);
