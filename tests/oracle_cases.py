@@ -125,8 +125,8 @@ def load(case, steps, oracle=None, compute_if_missing=True):
         return p, v, m, out
     missing = [os.path.basename(f) for f in files.values() if not os.path.exists(f)]
     if not compute_if_missing or c["n"] > 2_000_000 or oracle is None:
-        pytest.skip(f"{case}: {missing} not under tests/cache (scripts/oracle_cache.py {case} makes them; "
-                    f"hours of CPU at this size, not computed inside the suite)")
+        pytest.skip(f"{case}: {missing} not under tests/cache (scripts/oracle_cache.py {case} makes them in the build "
+                    f"container; too much host CPU to compute inside the suite)")
     print(f"  ({case}: {missing} not cached - computing the oracle here)")
     L = oracle.lib()
     L.nbref_set_num_threads(min(32, int(L.nbref_num_threads())))

@@ -29,7 +29,9 @@ def _errors(x, ref):
 def test_held_out_inputs_100_steps_default_precision(gpu, oracle, case):
     from nbody.gpu_backend import HIPBarnesHutSimulation
     c = oracle_cases.CASES[case]
-    p, v, m, ref = oracle_cases.load(case, (100,), oracle)
+    # without its cached trajectory only the small case is computed inside the suite (the 1 M oracles take 4 min each on
+    # the box's 32 host threads: seven of them would be the suite); the others skip with the reason
+    p, v, m, ref = oracle_cases.load(case, (100,), oracle, compute_if_missing=(oracle_cases.CASES[case]["n"] <= 200_000))
     sim = HIPBarnesHutSimulation(p, v, m, c["G"], c["eps"], 1.0, c["theta"])
     shares = []
     for k in range(1, 101):
