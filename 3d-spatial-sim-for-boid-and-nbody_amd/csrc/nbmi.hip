@@ -2091,20 +2091,37 @@ __global__ __launch_bounds__(kBlock) void k_direct(const float4 *__restrict__ po
         float sx[IB], sy[IB], sz[IB];
 #pragma unroll
         for (int k = 0; k < IB; k++) sx[k] = sy[k] = sz[k] = 0.f;
-#pragma unroll 8
-        for (int jj = 0; jj < kBlock; jj++) {
-            const float4 q = tile[jj];
+        // [r4] The j-bodies are fetched a chunk AHEAD: the next eight LDS reads are issued before the current eight bodies'
+        // arithmetic, so no read is waited for where it is issued (the compiler's 8-unrolled form of the plain loop put an
+        // s_waitcnt lgkmcnt(0) behind each of its last four ds_read_b128).  Same operations in the same order: results
+        // unchanged bit for bit.  62.8 -> 73.3 TFLOP/s at 1 M bodies (318 -> 273 ms per step) (scripts/ubench/direct_valu_sched.hip:
+        // 47.3 -> 41.2 cycles per 64 pairs per SIMD; chunks of 4: 41.9; more bodies per thread: no better).
+        constexpr int CH = 8;
+        float4 cur[CH], nxt[CH];
 #pragma unroll
-            for (int k = 0; k < IB; k++) {
-                const float dx = q.x - px[k], dy = q.y - py[k], dz = q.z - pz[k];
-                const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
-                const float inv = __builtin_amdgcn_rsqf(r2);
-                float f = q.w * inv * inv * inv;
-                if (kGuard) f = (r2 > 0.f) ? f : 0.f;
-                sx[k] = fmaf(f, dx, sx[k]);
-                sy[k] = fmaf(f, dy, sy[k]);
-                sz[k] = fmaf(f, dz, sz[k]);
+        for (int c = 0; c < CH; c++) cur[c] = tile[c];
+#pragma unroll 1
+        for (int jj = 0; jj < kBlock; jj += CH) {
+            const int nb = jj + CH < kBlock ? jj + CH : 0;
+#pragma unroll
+            for (int c = 0; c < CH; c++) nxt[c] = tile[nb + c];
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const float4 q = cur[c];
+#pragma unroll
+                for (int k = 0; k < IB; k++) {
+                    const float dx = q.x - px[k], dy = q.y - py[k], dz = q.z - pz[k];
+                    const float r2 = fmaf(dz, dz, fmaf(dy, dy, fmaf(dx, dx, eps2)));
+                    const float inv = __builtin_amdgcn_rsqf(r2);
+                    float f = q.w * inv * inv * inv;
+                    if (kGuard) f = (r2 > 0.f) ? f : 0.f;
+                    sx[k] = fmaf(f, dx, sx[k]);
+                    sy[k] = fmaf(f, dy, sy[k]);
+                    sz[k] = fmaf(f, dz, sz[k]);
+                }
             }
+#pragma unroll
+            for (int c = 0; c < CH; c++) cur[c] = nxt[c];
         }
 #pragma unroll
         for (int k = 0; k < IB; k++) {
