@@ -429,9 +429,10 @@ def test_direct_matches_oracle_mid_size(gpu, oracle):
     """All three register-blocking variants (1, 2, 4 bodies per thread), ragged sizes."""
     from nbody.gpu_backend import HIPDirectSimulation
     rng = np.random.RandomState(11)
-    for n in (1000, 131_073, 524_289):
+    for n, uniform in ((1000, False), (131_073, False), (524_289, False), (1001, True), (131_073, True)):
         pos = rng.normal(0, 100, (n, 3))
-        m = rng.uniform(0.5, 2.0, n)
+        # equal masses take the kernel variant with G m outside the pair loop ([r4]; ragged sizes: its far-away pads)
+        m = np.full(n, 1.5) if uniform else rng.uniform(0.5, 2.0, n)
         sim = HIPDirectSimulation(pos, np.zeros_like(pos), m, 0.05, 1.0, 1.0)
         acc = sim.accelerations()
         sample = rng.choice(n, 256, replace=False)
@@ -440,7 +441,7 @@ def test_direct_matches_oracle_mid_size(gpu, oracle):
         w = 0.05 * m[None, :] * r2 ** -1.5
         ref = (w[:, :, None] * d).sum(1)
         err = _rel_err(acc[sample], ref)
-        print(f"direct n={n}: rel err max {err.max():.3e}")
+        print(f"direct n={n}{' equal masses' if uniform else ''}: rel err max {err.max():.3e}")
         assert err.max() <= 5e-5
         sim.close()
 
