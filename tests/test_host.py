@@ -277,3 +277,20 @@ def test_frames_reach_their_name_only_complete(tmp_path):
         rec._atomically(tmp_path / "frame_0001.npz", dies)
     assert rec.get_completed_frames(tmp_path) == 1
     assert sorted(q.name for q in tmp_path.iterdir()) == ["frame_0000.npz"]
+
+
+def test_oracle_cache_manifest_covers_every_case_and_matches_the_files():
+    """tests/oracle_cases.py: every long-trajectory case has its hashes committed in tests/golden/MANIFEST.json, and
+    whatever is under tests/cache/ here is what those hashes say (a stale or regenerated file must not reach the GPU
+    suite unnoticed; the suite itself asserts the same on load)."""
+    import oracle_cases as oc
+    man = oc.manifest()
+    for case, c in oc.CASES.items():
+        assert case in man, f"{case}: no entry in MANIFEST.json (scripts/oracle_cache.py {case})"
+        names = {os.path.basename(oc.cache_file(case, k)) for k in c["keep"]}
+        assert names == set(man[case]["files"]), (case, sorted(names ^ set(man[case]["files"])))
+        assert man[case]["case"]["n"] == c["n"] and man[case]["case"]["dt"] == c["dt"] and man[case]["case"]["seed"] == c["seed"]
+        for name, want in man[case]["files"].items():
+            f = os.path.join(oc.CACHE, name)
+            if os.path.exists(f):
+                assert oc.sha256_file(f) == want, name
