@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
         // bounds -> candidates), not arithmetic: the three rows of a z plane go through each stage TOGETHER, so
         // that their loads are in flight at the same time.  Same rows, same order, same sums as the loop below.
         bool big = false;
+        int nr = 0;  // non-empty runs noted so far
         for (int dcz = -1; dcz <= 1; dcz++) {
             const int ncz = cz + dcz;
             const bool zok = ncz >= 0 && ncz < g.dim;
@@ -281,10 +282,14 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
                 }
             }
             // [r4] the runs are only noted here; ONE loop behind the three planes walks all nine (below)
+            // (only the NON-EMPTY runs are noted, in row order: the loop below then never has to step over an empty one)
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                runs[2 * (3 * (dcz + 1) + j)][threadIdx.x] = qb[j];
-                runs[2 * (3 * (dcz + 1) + j) + 1][threadIdx.x] = qe[j];
+                if (qe[j] > qb[j]) {
+                    runs[2 * nr][threadIdx.x] = qb[j];
+                    runs[2 * nr + 1][threadIdx.x] = qe[j];
+                    nr++;
+                }
                 big = big || qe[j] - qb[j] > 4095;
             }
         }
@@ -332,10 +337,11 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
             nh = 0;
         };
         int row = 0;
-        int32_t q = runs[0][threadIdx.x], e = runs[1][threadIdx.x], q_first = q;
+        int32_t q = 0, e = 0, q_first = 0;
+        if (nr > 0) { q = q_first = runs[0][threadIdx.x]; e = runs[1][threadIdx.x]; }
         auto next = [&](unsigned &code) -> int32_t {
-            while (q >= e) {
-                if (row >= 8) { row = 9; return -1; }
+            if (q >= e) {  // the run is used up: on to the next noted one (none of them is empty)
+                if (row + 1 >= nr) { row = nr; return -1; }
                 row++;
                 q = q_first = runs[2 * row][threadIdx.x];
                 e = runs[2 * row + 1][threadIdx.x];
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
         if (big) {
             // a run of more than 4095 boids (three cells!): its offsets do not fit the 16-bit notes - such a boid
             // takes its candidates one by one, as the loop for other grids below does
-            for (int k = 0; k < 9; k++)
+            for (int k = 0; k < nr; k++)
                 for (int32_t c = runs[2 * k][threadIdx.x]; c < runs[2 * k + 1][threadIdx.x]; c++) candidate(c);
         } else
         for (;;) {
