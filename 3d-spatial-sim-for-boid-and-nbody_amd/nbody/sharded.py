@@ -449,7 +449,12 @@ class LetBarnesHut:
             e.migrated = int(send_counts.sum())
 
     def gather_state(self):
-        """Full (positions, velocities) float64 in the caller's original order, on every rank."""
+        """Full (positions, velocities) float64 in the caller's original order, on every rank.  (A failure of this
+        rank's last walk that no later step has announced to the others yet is raised here, on this rank: its state is
+        not the state after that step.)"""
+        if self._carried is not None:
+            failed, self._carried = self._carried, None
+            raise failed
         ids, pos, vel = self.engine.owned_state()
         if self.world == 1:
             out_p, out_v = np.empty((self.n, 3)), np.empty((self.n, 3))
