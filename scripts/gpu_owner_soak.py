@@ -1,6 +1,7 @@
 """Owner mode over many steps: 8 virtual ranks (threads on one GPU, LetBarnesHut.step itself) against the single handle,
 both with float64 forces, every 100 steps - bodies migrate, rank boundaries wander through the tree, the pieces are
-re-cut every step.  python scripts/gpu_owner_soak.py [n] [world] [steps] [dist]"""
+re-cut every step.  python scripts/gpu_owner_soak.py [n] [world] [steps] [dist] [f64 | auto]
+(auto [r4]: the system-wide "every wave float64" verdict of the ranks against the single handle's, through a transition)"""
 import json
 import os
 import sys
@@ -18,6 +19,7 @@ def main():
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 500
     dist = sys.argv[4] if len(sys.argv) > 4 else "collision"
+    mode = sys.argv[5] if len(sys.argv) > 5 else "f64"
     from nbody.gpu_backend import HIPBarnesHutSimulation
     from nbody.sharded import HipLetEngine, LetBarnesHut
     from tools.presets import generate_distribution
@@ -26,11 +28,11 @@ def main():
     np.random.seed(5)
     pos, vel, mass = generate_distribution(dist, n, 600.0, G)
     single = HIPBarnesHutSimulation(pos, vel, mass, G, eps, 1.0, theta)
-    single.set_force_precision("f64")
+    single.set_force_precision(mode)
     comm = _ThreadComm(world)
     engines = [HipLetEngine(pos, vel, mass, G, eps, 1.0, theta, 0, r, world) for r in range(world)]
     for e in engines:
-        e.sim.set_force_precision("f64")
+        e.sim.set_force_precision(mode)
     steppers = [LetBarnesHut(e, r, world, comm.bind(r)) for r, e in enumerate(engines)]
     done = 0
     while done < steps:
@@ -41,7 +43,11 @@ def main():
         ref = single.get_positions_f64()
         done += k
         d = np.abs(out[0][0] - ref).max(axis=1) / np.abs(ref).max()
-        print(json.dumps({"dist": dist, "n": n, "world": world, "steps": done, "max_vs_single_f64": float(d.max()),
+        sh = single.force_precision_share()
+        print(json.dumps({"dist": dist, "n": n, "world": world, "mode": mode, "steps": done, "max_vs_single": float(d.max()),
+                          "single_share_all64": [round(sh[0], 3), bool(sh[1])],
+                          "ranks_all64": [int(e.sim.force_precision_share()[1]) for e in engines],
+                          "ranks_share": [round(e.sim.force_precision_share()[0], 3) for e in engines],
                           "owned": [int(e.sim.n) for e in engines], "let_rows": [int(e.let_counts.sum()) for e in engines],
                           "migrated_last_step": [int(e.migrated) for e in engines], "wall_s": round(time.time() - t0, 2)}), flush=True)
     for e in engines:
