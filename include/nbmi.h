@@ -143,7 +143,9 @@ int nbmi_walk_counters(nbmi_sim *sim, int64_t *out17);
  * {x,y,z,vx,vy,vz,m,id}.  Pointers are DEVICE pointers (e.g. torch tensors' data_ptr()) so the
  * exchange itself can be an RCCL all-gather issued by the host framework.  Results equal the unsharded
  * handle's bit for bit when `begin` is a multiple of 64 (a wave's 64 bodies, and with them the order of its
- * fp32 sums, are then the same however the ranks are cut; nbody/sharded.py::shard_bounds does that). */
+ * fp32 sums, are then the same however the ranks are cut; nbody/sharded.py::shard_bounds does that).  The rows carry
+ * every body's OWN mass: masses are fixed at creation (a direct-N^2 handle whose bodies all have the same mass takes
+ * G m out of its pair loop, decided once at nbmi_create). */
 int nbmi_set_shard(nbmi_sim *sim, int64_t begin, int64_t end);
 int nbmi_export_shard(nbmi_sim *sim, void *dev_rows);                              /* (end-begin, 8) f64 */
 int nbmi_import_ranks(nbmi_sim *sim, const void *dev_rows, int64_t begin, int64_t end);
