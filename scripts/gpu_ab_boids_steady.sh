@@ -1,5 +1,6 @@
 #!/bin/bash
-# boids: candidate-loop variants against earlier builds (t = 0 and after 1000 steps), parity suite first
+# boids A/B: the default library against PREV="lib1.so lib2.so" (files beside it), bench line at t = 0 and after 1000 steps, two
+# alternating rounds; parity suite first
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
