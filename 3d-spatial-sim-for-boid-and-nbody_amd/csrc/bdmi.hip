@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_flock(BoidsAoS b, Boids a, const uin
         // with their position records requested together, and notes the neighbours (16 bits each: row and offset in
         // the row's run) in a per-lane list in LDS; phase 2 walks that list - every lane busy with a real neighbour,
         // two at a time with all six records in flight.  Same neighbours in the same order: results unchanged bit
-        // for bit.  Sweep at 2 M boids: 0.275 -> 0.218 ms on the initial state, 0.783 -> 0.602 ms after 1000 steps.
+        // for bit.  Sweep at 2 M boids: 0.275 -> 0.205 ms on the initial state, 0.783 -> 0.579 ms after 1000 steps.
         // (Measured and dropped: phase 1 on an fp32 copy of the positions relative to the cell centres, eight per trip,
         // float64 re-test inside the fp32 error band - same sets, 0.67 ms: the sweep waits for its gathers, it is not
         // short of arithmetic or bytes.)

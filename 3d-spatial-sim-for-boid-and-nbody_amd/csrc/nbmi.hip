@@ -580,10 +580,11 @@ __global__ __launch_bounds__(kSubScanThreads) void k_scan_subtiles(const double4
         if (sub_flag) fl += sub_flag[i];
     }
     if (sub_flag) {
-        // [r3] force precision "auto": when more than half of the waves ask for float64, every wave gets it - where
-        // most of the system needs float64, the sparse rest interacts with the same massive cells (10 M collision at
-        // dt 0.25: the 5 % of the waves below any density threshold end at 3.8e-4 after 50 steps in fp32, at 1e-10 in
-        // float64; at the 1 M galaxy 30 % of the waves ask and the fp32 rest stays at 2e-6 after 100 steps)
+        // [r3, thresholds r4] force precision "auto": while a large part of the waves ask for float64 (all64_rule: entered
+        // above a third, left below a quarter), every wave gets it - where much of the system needs float64, the sparse rest
+        // interacts with the same massive cells (10 M collision at dt 0.25: the 5 % of the waves below any density threshold
+        // end at 3.8e-4 after 50 steps in fp32, at 1e-10 in float64; at the 1 M galaxy a quarter of the waves ask at first and
+        // the fp32 rest stays at 2e-6 after 100 steps)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) fl += __shfl_xor(fl, o);
         if (lane == 0) fsum[w] = fl;

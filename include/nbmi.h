@@ -269,7 +269,7 @@ int nbmi_set_exchange_sync(nbmi_sim *sim, int sync);
  * Environment NBMI_FORCE_PREC / NBMI_PREC_TAU set the initial values. */
 int nbmi_set_force_precision(nbmi_sim *sim, int mode, double tau);
 /* Mode 0, after a step: the share of the waves whose own density asked for float64, and whether the step ran every
- * wave in float64 (more than half asked). */
+ * wave in float64 (the system-wide rule above: entered when more than a third asked, left below a quarter). */
 int nbmi_force_precision_share(nbmi_sim *sim, double *share, int *all_float64);
 /* Native HIP stream of the handle (for ordering against framework streams). */
 void *nbmi_stream(nbmi_sim *sim);
